@@ -1,0 +1,202 @@
+/*
+ * ocl_rt_amd.h — C ABI of the MI355X (gfx950, HIP) path tracer that is a drop-in
+ * for the reference's OpenCL block-dispatch layer.
+ *
+ * The reference (WillBurland/OpenCL-Ray-Tracer) has no plugin interface: its
+ * render path is one OpenCL kernel, `pixel_colour`, driven by a linear run of
+ * OpenCL host calls inside main() (src/cpp/main.cpp:25-77,160-205,229-247).
+ * Each entry point below replaces one group of those calls and says which.
+ * All structs are the reference's PODs, byte for byte
+ * (src/opencl/gpu_kernel.cl:3-69 == src/cpp/opencl_objects/cl_*.hpp).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative wbrt_status otherwise;
+ *     wbrt_last_error() returns a human-readable message for the calling thread;
+ *   - the library copies on upload: the caller may free host arrays right away
+ *     (the reference mallocs and never frees: main.cpp:81,95,99,113,123-124,144,148);
+ *   - a context is bound to one GPU and must be used from one thread at a time
+ *     (the reference is single-threaded with one in-order queue: main.cpp:175);
+ *   - images are row-major, 3 floats per pixel, row 0 = BOTTOM row of the picture
+ *     (gpu_kernel.cl:626-627, main.cpp:250-259).
+ */
+#ifndef OCL_RT_AMD_H
+#define OCL_RT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ PODs */
+typedef struct { float x, y, z; } wbrt_vec3;                    /* gpu_kernel.cl:3-6    cl_vec3.hpp:8-11    12 B */
+typedef struct { wbrt_vec3 albedo; float fuzz; float ior; int32_t type; } wbrt_material; /* :15-21 cl_material.hpp:6-12 24 B */
+typedef struct { wbrt_vec3 center; float radius; wbrt_material material; } wbrt_sphere;  /* :23-28 cl_sphere.hpp:7-12   40 B */
+typedef struct { wbrt_vec3 p0, p1, p2; wbrt_material material; int32_t boundingBoxId; } wbrt_triangle; /* :30-35 cl_triangle.hpp:7-12 64 B */
+typedef struct { int32_t id; wbrt_vec3 min, max; } wbrt_bounding_box;                     /* :37-42 cl_bounding_box.hpp:6-10 28 B */
+typedef struct
+{
+	wbrt_vec3 origin, horizontal, vertical, lowerLeftCorner;
+	wbrt_vec3 defocusDiscU, defocusDiscV;
+	wbrt_vec3 blockSize;    /* block width/height in pixels, stored as floats (main.cpp:92) */
+	wbrt_vec3 blockOffset;  /* block INDEX (x, y, 0) as floats (main.cpp:234) */
+	int32_t width, height, samplesPerPixel, maxDepth;
+	float focusDistance, aperture;
+} wbrt_camera;                                                   /* gpu_kernel.cl:53-69  cl_camera.hpp:6-22  120 B */
+
+/* material.type values (gpu_kernel.cl:282-330) */
+enum { WBRT_LAMBERTIAN = 0, WBRT_METAL = 1, WBRT_DIELECTRIC = 2, WBRT_EMISSIVE = 3 };
+
+typedef enum
+{
+	WBRT_OK = 0,
+	WBRT_ERR_INVALID = -1,     /* bad argument / scene not uploaded / size mismatch */
+	WBRT_ERR_NO_DEVICE = -2,   /* no usable HIP device */
+	WBRT_ERR_HIP = -3,         /* a HIP runtime call failed (message has the hipError name) */
+	WBRT_ERR_OOM = -4,
+	WBRT_ERR_IO = -5
+} wbrt_status;
+
+/* what a render writes per pixel */
+enum
+{
+	WBRT_OUT_MEAN = 0,        /* clamped per-sample sum / samplesPerPixel: the reference's output (gpu_kernel.cl:647) */
+	WBRT_OUT_SUM = 1,         /* clamped per-sample sum, not divided (one samples-per-pixel shard) */
+	WBRT_OUT_ACCUMULATE = 2   /* image += clamped per-sample sum (shards summed on the device) */
+};
+
+typedef struct wbrt_context wbrt_context;
+
+const char *wbrt_last_error(void);
+
+/* ------------------------------------------------ device path (HIP, gfx950) */
+
+/* replaces cl::Device/Platform::getDefault, cl::Context, cl::Program::build,
+ * cl::Kernel and cl::CommandQueue (main.cpp:27-29,38-51,175) */
+int wbrt_create(int device_ordinal, wbrt_context **out);
+int wbrt_destroy(wbrt_context *ctx);
+
+/* replaces the sphere / triangle / bounding-box buffers, their count buffers and
+ * blocking writes (main.cpp:168-173,185-190) and setArg 6-11 (main.cpp:200-205).
+ * Any pointer may be NULL when its count is 0. */
+int wbrt_upload_scene(wbrt_context *ctx, const wbrt_sphere *spheres, int32_t sphere_count,
+                      const wbrt_triangle *triangles, int32_t triangle_count,
+                      const wbrt_bounding_box *boxes, int32_t box_count);
+
+/* replaces bufferHDRImageData + width/height buffers (main.cpp:163-165,180-182,195-197).
+ * texels: width*height, row-major, already tone-mapped to [0,1] (utility.cpp:172-190).
+ * The device copy is followed by width+1 zero guard texels: the kernel's texel index
+ * reaches one row past the end when u or v is exactly 1 (gpu_kernel.cl:343-345). */
+int wbrt_upload_sky(wbrt_context *ctx, const wbrt_vec3 *texels, int32_t width, int32_t height);
+
+/* replaces bufferRandomSeeds (main.cpp:166,183,198).  seeds[i] is read by in-block
+ * work-item i of EVERY block (gpu_kernel.cl:604-606); n must be >= block pixels. */
+int wbrt_upload_seeds(wbrt_context *ctx, const uint32_t *seeds, size_t n);
+
+/* replaces one iteration of the block loop: camera upload + setArg(5) +
+ * enqueueNDRangeKernel + blocking enqueueReadBuffer (main.cpp:234-247).
+ * out_block: blockSize.x*blockSize.y texels indexed by in-block id (row 0 = bottom). */
+int wbrt_render_block(wbrt_context *ctx, const wbrt_camera *camera, wbrt_vec3 *out_block);
+
+/* replaces the whole block loop (main.cpp:229-260) with ONE launch over every block;
+ * blockOffset in *camera is ignored, blockSize selects the tiling (and therefore the
+ * seed indexing).  host_image: width*height texels, row 0 = bottom.  Blocking. */
+int wbrt_render_frame(wbrt_context *ctx, const wbrt_camera *camera, int out_mode, float *host_image);
+
+/* same, into DEVICE memory (width*height*3 floats) on `stream` (a hipStream_t, NULL =
+ * the default stream); asynchronous.  For WBRT_OUT_ACCUMULATE the image must hold valid
+ * data (e.g. zeros).  No counterpart in the reference (it reads every block back). */
+int wbrt_render_frame_device(wbrt_context *ctx, const wbrt_camera *camera, int out_mode,
+                             void *device_image, void *stream);
+
+/* Primary-hit primitive id per pixel for sample 0's first ray segment: sphere index,
+ * sphere_count + triangle index, or -1 (miss).  No counterpart in the reference
+ * (its HitRecord carries no id, gpu_kernel.cl:44-51); it exists for parity checking.
+ * host_ids: width*height int32, row 0 = bottom. */
+int wbrt_primary_ids_frame(wbrt_context *ctx, const wbrt_camera *camera, int32_t *host_ids);
+
+/* Event counters of one frame render (same events, same order as wbo_counters in
+ * oracle/pt_oracle.h); used to price the algorithmic FLOPs of a workload.
+ * counters: 26 x uint64.  Slow (instrumented kernel); never timed. */
+int wbrt_count_events_frame(wbrt_context *ctx, const wbrt_camera *camera, uint64_t *counters);
+
+/* replaces WriteColour (colour.cpp:5-15) on the device: gamma 2, *255, truncation.
+ * scale multiplies the texel first (1/samplesPerPixel for a summed image, else 1).
+ * device_rgb8: width*height*3 bytes, R,G,B order, row 0 = TOP (PPM order). */
+int wbrt_tonemap_device(wbrt_context *ctx, const void *device_image, float scale,
+                        int32_t width, int32_t height, void *device_rgb8, void *stream);
+
+int wbrt_synchronize(wbrt_context *ctx);
+
+/* kernel-only timing: when enabled every render launch is bracketed by HIP events on
+ * its own stream.  wbrt_get_timing synchronises and returns the sum over launches since
+ * the last reset. */
+int wbrt_set_timing(wbrt_context *ctx, int enable);
+int wbrt_get_timing(wbrt_context *ctx, double *total_ms, int32_t *launches, int reset);
+
+/* device facts for the harness log (replaces PrintOpenCLInfo, utility.cpp:3-61) */
+int wbrt_device_info(wbrt_context *ctx, char *buf, size_t buf_len);
+
+/* ------------------------------------- host helpers (reference host functions) */
+
+/* CalculateCamera (cl_camera.cpp:3-45); width/height/spp/depth are runtime values
+ * here (macros in globals.hpp:8-14).  aperture is a defocus ANGLE in degrees. */
+void wbrt_calculate_camera(wbrt_camera *camera, wbrt_vec3 look_from, wbrt_vec3 look_at, wbrt_vec3 v_up,
+                           float v_fov, float aspect_ratio, float focus_distance, float aperture,
+                           int32_t width, int32_t height, int32_t samples_per_pixel, int32_t max_depth);
+
+/* IMAGE_HEIGHT = (int)(IMAGE_WIDTH / ASPECT_RATIO) in double (globals.hpp:8-10) */
+int32_t wbrt_image_height(int32_t width, double aspect_ratio);
+
+/* GetIdealBlockSize(width*height, target_blocks) (utility.cpp:192-236, main.cpp:65) */
+wbrt_vec3 wbrt_ideal_block_size(int32_t width, int32_t height, int32_t target_blocks);
+
+/* deterministic replacement for srand(time)/rand() seeding (main.cpp:18,148-152):
+ * seeds[i] = low 32 bits of (r*0x5DEECE66D + 0xB) with r a 31-bit SplitMix64 draw */
+void wbrt_make_seeds(uint64_t base_seed, uint32_t shard, uint32_t *seeds, size_t n);
+
+/* WriteColour (colour.cpp:5-15) for a whole image: rgb8 R,G,B order, row 0 = TOP */
+void wbrt_tonemap_host(const float *image, float scale, int32_t width, int32_t height, uint8_t *rgb8);
+
+/* headless writers replacing the Win32 window + output.bmp (main.cpp:262-265) */
+int wbrt_write_ppm(const char *path, const uint8_t *rgb8, int32_t width, int32_t height);
+int wbrt_write_pfm(const char *path, const float *image, int32_t width, int32_t height);
+/* generateBitmapImage (bitmap_io.cpp:3-29): 24-bit bottom-up BMP from top-down RGB8 */
+int wbrt_write_bmp(const char *path, const uint8_t *rgb8, int32_t width, int32_t height);
+
+/* OBJ loader: GetNumOfVertices/GetNumOfFaces/ReadMeshData (utility.cpp:63-170) with the
+ * bounding-box initialisation of main.cpp:114-115.  Call with triangles == NULL to get
+ * the counts; then with arrays of those sizes. */
+int wbrt_read_mesh(const char *path, wbrt_vec3 scale, wbrt_vec3 translate, wbrt_material material,
+                   int32_t bounding_box_id, wbrt_triangle *triangles, int32_t *triangle_count,
+                   int32_t *vertex_count, wbrt_vec3 *box_min, wbrt_vec3 *box_max);
+
+/* sky tone map of ReadHdrImageData (utility.cpp:172-190): c' = 1 + 1/pow(-1-c, 5) */
+void wbrt_sky_tonemap(const float *rgb_in, size_t n_texels, wbrt_vec3 *out);
+/* Radiance .hdr reader (lib/hdrloader.cpp:29-191); *rgb is malloc'd, free with wbrt_free */
+int wbrt_load_hdr(const char *path, int32_t *width, int32_t *height, float **rgb);
+void wbrt_free(void *p);
+
+/* ------------------------------------------------ scene fixtures of the harness */
+/* README.md:32-38 five-sphere scene; returns the count written (<= max) */
+int32_t wbrt_scene_readme(wbrt_sphere *spheres, int32_t max);
+/* main.cpp:98-107 eight-sphere scene */
+int32_t wbrt_scene_main_cpp(wbrt_sphere *spheres, int32_t max);
+/* main.cpp:81-92 camera (fov 60, focus 2, aperture 1.2 deg) and the README-scene camera
+ * (not recorded by the reference: look from origin down -z, fov 90, no defocus) */
+void wbrt_camera_main_cpp(wbrt_camera *camera, int32_t width, int32_t spp, int32_t depth);
+void wbrt_camera_readme(wbrt_camera *camera, int32_t width, int32_t spp, int32_t depth);
+/* synthetic equirectangular sky (the reference's skybox.hdr is not in its checkout):
+ * per-row blend white -> (0.5,0.7,1.0), already in [0,1] */
+void wbrt_sky_gradient(wbrt_vec3 *texels, int32_t width, int32_t height);
+/* divergence-stress scene: n random Lambertian/metal spheres from base_seed */
+int32_t wbrt_scene_stress_spheres(wbrt_sphere *spheres, int32_t n, uint64_t base_seed);
+/* procedural height-field mesh, (2*nx*nz) triangles split into boxes_x*boxes_z bounding boxes */
+int32_t wbrt_scene_stress_mesh(wbrt_triangle *triangles, wbrt_bounding_box *boxes,
+                               int32_t nx, int32_t nz, int32_t boxes_x, int32_t boxes_z, uint64_t base_seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

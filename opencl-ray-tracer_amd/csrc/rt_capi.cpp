@@ -1,0 +1,464 @@
+// Device half of the C ABI (include/ocl_rt_amd.h): context, uploads with repacking,
+// launches, read-back.  Replaces the OpenCL host calls of the reference's main()
+// (src/cpp/main.cpp:25-77,160-205,229-247); each entry point cites its lines in the header.
+#include "../../include/ocl_rt_amd.h"
+#include "rt_device.h"
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
+
+void wbrt_set_error_(const char *msg);
+
+namespace {
+
+int fail(int code, const std::string &msg)
+{
+	wbrt_set_error_(msg.c_str());
+	return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+	do {                                                                                    \
+		hipError_t e_ = (expr);                                                             \
+		if (e_ != hipSuccess)                                                               \
+			return fail(e_ == hipErrorOutOfMemory ? WBRT_ERR_OOM : WBRT_ERR_HIP,           \
+			            std::string(#expr) + ": " + hipGetErrorName(e_) + " (" + hipGetErrorString(e_) + ")"); \
+	} while (0)
+
+struct DevBuf
+{
+	void *p = nullptr;
+	size_t bytes = 0;
+	int upload(const void *src, size_t n)
+	{
+		if (n > bytes || !p)
+		{
+			if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+			size_t cap = n ? n : 16;
+			HIP_TRY(hipMalloc(&p, cap));
+			bytes = cap;
+		}
+		if (n) HIP_TRY(hipMemcpy(p, src, n, hipMemcpyHostToDevice));
+		return WBRT_OK;
+	}
+	int reserve(size_t n)
+	{
+		if (n <= bytes && p) return WBRT_OK;
+		if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+		HIP_TRY(hipMalloc(&p, n ? n : 16));
+		bytes = n ? n : 16;
+		return WBRT_OK;
+	}
+	void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+} // namespace
+
+struct wbrt_context
+{
+	int device = 0;
+	hipStream_t stream = nullptr; // used by the blocking entry points
+	DevBuf sph_geom, sph_radius, sph_mat_a, sph_mat_b;
+	DevBuf tri_geom, tri_mat_a, tri_mat_b, tri_orig;
+	DevBuf box_min, box_max, box_range;
+	DevBuf sky, seeds, image, ids, counters, rgb8;
+	SceneDev sc{};
+	bool have_scene = false, have_sky = false;
+	size_t n_seeds = 0;
+	bool timing = false;
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+};
+
+namespace {
+
+int bind(wbrt_context *ctx)
+{
+	if (!ctx) return fail(WBRT_ERR_INVALID, "null context");
+	HIP_TRY(hipSetDevice(ctx->device));
+	return WBRT_OK;
+}
+
+// Fills launch parameters from the camera; validates what the kernels assume.
+int make_params(wbrt_context *ctx, const wbrt_camera *cam, bool whole_frame, RenderParams &p)
+{
+	if (!cam) return fail(WBRT_ERR_INVALID, "null camera");
+	if (!ctx->have_scene) return fail(WBRT_ERR_INVALID, "no scene uploaded (wbrt_upload_scene)");
+	if (!ctx->have_sky) return fail(WBRT_ERR_INVALID, "no sky uploaded (wbrt_upload_sky)");
+	const int bsx = (int)cam->blockSize.x, bsy = (int)cam->blockSize.y; // gpu_kernel.cl:618-619
+	if (bsx <= 0 || bsy <= 0) return fail(WBRT_ERR_INVALID, "camera.blockSize must be positive");
+	if (cam->width <= 0 || cam->height <= 0) return fail(WBRT_ERR_INVALID, "camera width/height must be positive");
+	if (cam->samplesPerPixel < 0) return fail(WBRT_ERR_INVALID, "samplesPerPixel must be >= 0");
+	if ((size_t)bsx * (size_t)bsy > ctx->n_seeds)
+		return fail(WBRT_ERR_INVALID, "seed buffer smaller than one block (wbrt_upload_seeds)");
+	if ((long long)cam->width * cam->height > (1LL << 30)) return fail(WBRT_ERR_INVALID, "image too large");
+	std::memset(&p, 0, sizeof p);
+	const wbrt_vec3 *src[6] = { &cam->origin, &cam->horizontal, &cam->vertical, &cam->lowerLeftCorner,
+	                            &cam->defocusDiscU, &cam->defocusDiscV };
+	float *dst[6] = { p.org, p.hor, p.ver, p.llc, p.ddu, p.ddv };
+	for (int i = 0; i < 6; ++i) { dst[i][0] = src[i]->x; dst[i][1] = src[i]->y; dst[i][2] = src[i]->z; }
+	p.aperture = cam->aperture;
+	p.width = cam->width; p.height = cam->height;
+	p.spp = cam->samplesPerPixel; p.max_depth = cam->maxDepth;
+	p.bsx = bsx; p.bsy = bsy;
+	if (whole_frame)
+	{
+		if (cam->width % bsx || cam->height % bsy)
+			return fail(WBRT_ERR_INVALID, "blockSize must divide the image (main.cpp:222-223)");
+		p.nbx = cam->width / bsx; p.nby = cam->height / bsy;
+		p.off_bx = 0; p.off_by = 0;
+		p.out_w = cam->width;
+	}
+	else
+	{
+		p.nbx = 1; p.nby = 1;
+		p.off_bx = (int)cam->blockOffset.x; p.off_by = (int)cam->blockOffset.y;
+		p.out_w = bsx;
+	}
+	p.seeds = (const uint32_t *)ctx->seeds.p;
+	p.sc = ctx->sc;
+	return WBRT_OK;
+}
+
+int timed_launch(wbrt_context *ctx, const RenderParams &p, hipStream_t stream)
+{
+	hipEvent_t a = nullptr, b = nullptr;
+	if (ctx->timing)
+	{
+		HIP_TRY(hipEventCreate(&a));
+		HIP_TRY(hipEventCreate(&b));
+		HIP_TRY(hipEventRecord(a, stream));
+	}
+	HIP_TRY(wbrt_launch_render(p, stream));
+	if (ctx->timing)
+	{
+		HIP_TRY(hipEventRecord(b, stream));
+		ctx->events.emplace_back(a, b);
+	}
+	return WBRT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int wbrt_create(int device_ordinal, wbrt_context **out)
+{
+	if (!out) return fail(WBRT_ERR_INVALID, "null out pointer");
+	*out = nullptr;
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess || n <= 0) return fail(WBRT_ERR_NO_DEVICE, "no HIP device available");
+	if (device_ordinal < 0 || device_ordinal >= n) return fail(WBRT_ERR_INVALID, "device ordinal out of range");
+	HIP_TRY(hipSetDevice(device_ordinal));
+	hipDeviceProp_t prop;
+	HIP_TRY(hipGetDeviceProperties(&prop, device_ordinal));
+	if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+		return fail(WBRT_ERR_NO_DEVICE, std::string("kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+	wbrt_context *ctx = new wbrt_context();
+	ctx->device = device_ordinal;
+	e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+	if (e != hipSuccess) { delete ctx; return fail(WBRT_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorName(e)); }
+	*out = ctx;
+	return WBRT_OK;
+}
+
+int wbrt_destroy(wbrt_context *ctx)
+{
+	if (!ctx) return WBRT_OK;
+	(void)hipSetDevice(ctx->device);
+	(void)hipDeviceSynchronize();
+	for (auto &ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+	DevBuf *all[] = { &ctx->sph_geom, &ctx->sph_radius, &ctx->sph_mat_a, &ctx->sph_mat_b, &ctx->tri_geom,
+	                  &ctx->tri_mat_a, &ctx->tri_mat_b, &ctx->tri_orig, &ctx->box_min, &ctx->box_max,
+	                  &ctx->box_range, &ctx->sky, &ctx->seeds, &ctx->image, &ctx->ids, &ctx->counters, &ctx->rgb8 };
+	for (DevBuf *b : all) b->release();
+	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+	delete ctx;
+	return WBRT_OK;
+}
+
+int wbrt_upload_scene(wbrt_context *ctx, const wbrt_sphere *spheres, int32_t S,
+                      const wbrt_triangle *tris, int32_t T, const wbrt_bounding_box *boxes, int32_t B)
+{
+	int rc = bind(ctx);
+	if (rc) return rc;
+	if (S < 0 || T < 0 || B < 0) return fail(WBRT_ERR_INVALID, "negative primitive count");
+	if ((S && !spheres) || (T && !tris) || (B && !boxes)) return fail(WBRT_ERR_INVALID, "null primitive array");
+	HIP_TRY(hipDeviceSynchronize());
+
+	// spheres -> SoA; radius*radius is one rounding, as in gpu_kernel.cl:460
+	std::vector<float4> geom((size_t)S), mat_a((size_t)S);
+	std::vector<float> radius((size_t)S);
+	std::vector<float2> mat_b((size_t)S);
+	for (int i = 0; i < S; ++i)
+	{
+		const wbrt_sphere &s = spheres[i];
+		volatile float r2 = s.radius * s.radius;
+		geom[(size_t)i] = make_float4(s.center.x, s.center.y, s.center.z, r2);
+		radius[(size_t)i] = s.radius;
+		mat_a[(size_t)i] = make_float4(s.material.albedo.x, s.material.albedo.y, s.material.albedo.z, s.material.fuzz);
+		float ty; std::memcpy(&ty, &s.material.type, 4);
+		mat_b[(size_t)i] = make_float2(s.material.ior, ty);
+	}
+	// triangles grouped by the bounding-box INDEX they name (gpu_kernel.cl:380 compares
+	// boundingBoxId with the loop index, not with BoundingBox.id), original order kept inside
+	// a group (first triangle wins ties, gpu_kernel.cl:520); others are never tested.
+	std::vector<int> first((size_t)B + 1, 0);
+	for (int j = 0; j < T; ++j)
+	{
+		int b = tris[j].boundingBoxId;
+		if (b >= 0 && b < B) first[(size_t)b + 1]++;
+	}
+	for (int b = 0; b < B; ++b) first[(size_t)b + 1] += first[(size_t)b];
+	const int Tg = B ? first[(size_t)B] : 0;
+	std::vector<float4> tgeom((size_t)Tg * 3), tmat_a((size_t)Tg);
+	std::vector<float2> tmat_b((size_t)Tg);
+	std::vector<int> torig((size_t)Tg);
+	std::vector<int> cursor(first.begin(), first.end());
+	for (int j = 0; j < T; ++j)
+	{
+		const wbrt_triangle &t = tris[j];
+		int b = t.boundingBoxId;
+		if (b < 0 || b >= B) continue;
+		size_t k = (size_t)cursor[(size_t)b]++;
+		volatile float e0x = t.p1.x - t.p0.x, e0y = t.p1.y - t.p0.y, e0z = t.p1.z - t.p0.z; // gpu_kernel.cl:491
+		volatile float e1x = t.p2.x - t.p0.x, e1y = t.p2.y - t.p0.y, e1z = t.p2.z - t.p0.z; // gpu_kernel.cl:492
+		tgeom[3 * k + 0] = make_float4(t.p0.x, t.p0.y, t.p0.z, e0x);
+		tgeom[3 * k + 1] = make_float4(e0y, e0z, e1x, e1y);
+		tgeom[3 * k + 2] = make_float4(e1z, 0.0f, 0.0f, 0.0f);
+		tmat_a[k] = make_float4(t.material.albedo.x, t.material.albedo.y, t.material.albedo.z, t.material.fuzz);
+		float ty; std::memcpy(&ty, &t.material.type, 4);
+		tmat_b[k] = make_float2(t.material.ior, ty);
+		torig[k] = j;
+	}
+	std::vector<float4> bmin((size_t)B), bmax((size_t)B);
+	std::vector<int2> brange((size_t)B);
+	for (int b = 0; b < B; ++b)
+	{
+		bmin[(size_t)b] = make_float4(boxes[b].min.x, boxes[b].min.y, boxes[b].min.z, 0.0f);
+		bmax[(size_t)b] = make_float4(boxes[b].max.x, boxes[b].max.y, boxes[b].max.z, 0.0f);
+		brange[(size_t)b] = make_int2(first[(size_t)b], first[(size_t)b + 1]);
+	}
+#define UP(buf, vec) do { rc = ctx->buf.upload((vec).data(), (vec).size() * sizeof((vec)[0])); if (rc) return rc; } while (0)
+	UP(sph_geom, geom); UP(sph_radius, radius); UP(sph_mat_a, mat_a); UP(sph_mat_b, mat_b);
+	UP(tri_geom, tgeom); UP(tri_mat_a, tmat_a); UP(tri_mat_b, tmat_b); UP(tri_orig, torig);
+	UP(box_min, bmin); UP(box_max, bmax); UP(box_range, brange);
+#undef UP
+	SceneDev &sc = ctx->sc;
+	sc.sph_geom = (const float4 *)ctx->sph_geom.p; sc.sph_radius = (const float *)ctx->sph_radius.p;
+	sc.sph_mat_a = (const float4 *)ctx->sph_mat_a.p; sc.sph_mat_b = (const float2 *)ctx->sph_mat_b.p;
+	sc.S = S;
+	sc.tri_geom = (const float4 *)ctx->tri_geom.p; sc.tri_mat_a = (const float4 *)ctx->tri_mat_a.p;
+	sc.tri_mat_b = (const float2 *)ctx->tri_mat_b.p; sc.tri_orig = (const int *)ctx->tri_orig.p;
+	sc.T = Tg;
+	sc.box_min = (const float4 *)ctx->box_min.p; sc.box_max = (const float4 *)ctx->box_max.p;
+	sc.box_range = (const int2 *)ctx->box_range.p;
+	sc.B = B;
+	ctx->have_scene = true;
+	return WBRT_OK;
+}
+
+int wbrt_upload_sky(wbrt_context *ctx, const wbrt_vec3 *texels, int32_t width, int32_t height)
+{
+	int rc = bind(ctx);
+	if (rc) return rc;
+	if (!texels || width <= 0 || height <= 0) return fail(WBRT_ERR_INVALID, "bad sky image");
+	HIP_TRY(hipDeviceSynchronize());
+	size_t n = (size_t)width * height, guard = (size_t)width + 1;
+	std::vector<float> buf((n + guard) * 3, 0.0f);
+	std::memcpy(buf.data(), texels, n * sizeof(wbrt_vec3));
+	rc = ctx->sky.upload(buf.data(), buf.size() * sizeof(float));
+	if (rc) return rc;
+	ctx->sc.sky = (const float *)ctx->sky.p;
+	ctx->sc.skyw = width; ctx->sc.skyh = height;
+	ctx->have_sky = true;
+	return WBRT_OK;
+}
+
+int wbrt_upload_seeds(wbrt_context *ctx, const uint32_t *seeds, size_t n)
+{
+	int rc = bind(ctx);
+	if (rc) return rc;
+	if (!seeds || !n) return fail(WBRT_ERR_INVALID, "empty seed buffer");
+	HIP_TRY(hipDeviceSynchronize());
+	rc = ctx->seeds.upload(seeds, n * sizeof(uint32_t));
+	if (rc) return rc;
+	ctx->n_seeds = n;
+	return WBRT_OK;
+}
+
+int wbrt_render_block(wbrt_context *ctx, const wbrt_camera *camera, wbrt_vec3 *out_block)
+{
+	int rc = bind(ctx);
+	if (rc) return rc;
+	if (!out_block) return fail(WBRT_ERR_INVALID, "null output");
+	RenderParams p;
+	rc = make_params(ctx, camera, false, p);
+	if (rc) return rc;
+	size_t bytes = (size_t)p.bsx * p.bsy * 3 * sizeof(float);
+	rc = ctx->image.reserve(bytes);
+	if (rc) return rc;
+	p.out = (float *)ctx->image.p;
+	p.out_mode = WBRT_OUT_MEAN;
+	rc = timed_launch(ctx, p, ctx->stream);
+	if (rc) return rc;
+	HIP_TRY(hipMemcpyAsync(out_block, p.out, bytes, hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	return WBRT_OK;
+}
+
+int wbrt_render_frame_device(wbrt_context *ctx, const wbrt_camera *camera, int out_mode, void *device_image, void *stream)
+{
+	int rc = bind(ctx);
+	if (rc) return rc;
+	if (!device_image) return fail(WBRT_ERR_INVALID, "null device image");
+	if (out_mode < 0 || out_mode > 2) return fail(WBRT_ERR_INVALID, "bad out_mode");
+	RenderParams p;
+	rc = make_params(ctx, camera, true, p);
+	if (rc) return rc;
+	p.out = (float *)device_image;
+	p.out_mode = out_mode;
+	return timed_launch(ctx, p, (hipStream_t)stream);
+}
+
+int wbrt_render_frame(wbrt_context *ctx, const wbrt_camera *camera, int out_mode, float *host_image)
+{
+	int rc = bind(ctx);
+	if (rc) return rc;
+	if (!host_image || !camera) return fail(WBRT_ERR_INVALID, "null argument");
+	if (camera->width <= 0 || camera->height <= 0) return fail(WBRT_ERR_INVALID, "camera width/height must be positive");
+	size_t bytes = (size_t)camera->width * camera->height * 3 * sizeof(float);
+	rc = ctx->image.reserve(bytes);
+	if (rc) return rc;
+	if (out_mode == WBRT_OUT_ACCUMULATE)
+		HIP_TRY(hipMemcpyAsync(ctx->image.p, host_image, bytes, hipMemcpyHostToDevice, ctx->stream));
+	rc = wbrt_render_frame_device(ctx, camera, out_mode, ctx->image.p, ctx->stream);
+	if (rc) return rc;
+	HIP_TRY(hipMemcpyAsync(host_image, ctx->image.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	return WBRT_OK;
+}
+
+int wbrt_primary_ids_frame(wbrt_context *ctx, const wbrt_camera *camera, int32_t *host_ids)
+{
+	int rc = bind(ctx);
+	if (rc) return rc;
+	if (!host_ids) return fail(WBRT_ERR_INVALID, "null output");
+	RenderParams p;
+	rc = make_params(ctx, camera, true, p);
+	if (rc) return rc;
+	size_t bytes = (size_t)p.width * p.height * sizeof(int32_t);
+	rc = ctx->ids.reserve(bytes);
+	if (rc) return rc;
+	p.ids = (int *)ctx->ids.p;
+	HIP_TRY(wbrt_launch_ids(p, ctx->stream));
+	HIP_TRY(hipMemcpyAsync(host_ids, p.ids, bytes, hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	return WBRT_OK;
+}
+
+int wbrt_count_events_frame(wbrt_context *ctx, const wbrt_camera *camera, uint64_t *counters)
+{
+	int rc = bind(ctx);
+	if (rc) return rc;
+	if (!counters) return fail(WBRT_ERR_INVALID, "null output");
+	RenderParams p;
+	rc = make_params(ctx, camera, true, p);
+	if (rc) return rc;
+	size_t bytes = WBRT_NUM_COUNTERS * sizeof(unsigned long long);
+	rc = ctx->counters.reserve(bytes);
+	if (rc) return rc;
+	HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, bytes, ctx->stream));
+	p.counters = (unsigned long long *)ctx->counters.p;
+	HIP_TRY(wbrt_launch_count(p, ctx->stream));
+	HIP_TRY(hipMemcpyAsync(counters, p.counters, bytes, hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	return WBRT_OK;
+}
+
+int wbrt_tonemap_device(wbrt_context *ctx, const void *device_image, float scale,
+                        int32_t width, int32_t height, void *device_rgb8, void *stream)
+{
+	int rc = bind(ctx);
+	if (rc) return rc;
+	if (!device_image || !device_rgb8 || width <= 0 || height <= 0) return fail(WBRT_ERR_INVALID, "bad tonemap argument");
+	HIP_TRY(wbrt_launch_tonemap((const float *)device_image, scale, width, height, (uint8_t *)device_rgb8, (hipStream_t)stream));
+	return WBRT_OK;
+}
+
+int wbrt_synchronize(wbrt_context *ctx)
+{
+	int rc = bind(ctx);
+	if (rc) return rc;
+	HIP_TRY(hipDeviceSynchronize());
+	return WBRT_OK;
+}
+
+int wbrt_set_timing(wbrt_context *ctx, int enable)
+{
+	if (!ctx) return fail(WBRT_ERR_INVALID, "null context");
+	ctx->timing = enable != 0;
+	return WBRT_OK;
+}
+
+int wbrt_get_timing(wbrt_context *ctx, double *total_ms, int32_t *launches, int reset)
+{
+	int rc = bind(ctx);
+	if (rc) return rc;
+	double sum = 0.0;
+	for (auto &ev : ctx->events)
+	{
+		HIP_TRY(hipEventSynchronize(ev.second));
+		float ms = 0.0f;
+		HIP_TRY(hipEventElapsedTime(&ms, ev.first, ev.second));
+		sum += ms;
+	}
+	if (total_ms) *total_ms = sum;
+	if (launches) *launches = (int32_t)ctx->events.size();
+	if (reset)
+	{
+		for (auto &ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+		ctx->events.clear();
+	}
+	return WBRT_OK;
+}
+
+int wbrt_device_info(wbrt_context *ctx, char *buf, size_t buf_len)
+{
+	int rc = bind(ctx);
+	if (rc) return rc;
+	if (!buf || !buf_len) return fail(WBRT_ERR_INVALID, "null buffer");
+	hipDeviceProp_t prop;
+	HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
+	std::snprintf(buf, buf_len,
+	              "device %d: %s (%s), %d CUs, %d MHz, %.1f GiB, LDS/block %zu B, wave %d",
+	              ctx->device, prop.name, prop.gcnArchName, prop.multiProcessorCount, prop.clockRate / 1000,
+	              (double)prop.totalGlobalMem / (1024.0 * 1024.0 * 1024.0), prop.sharedMemPerBlock, prop.warpSize);
+	return WBRT_OK;
+}
+
+// Test hook (not in the public header): runs the device's float primitives on arrays.
+int wbrt_math_probe_(wbrt_context *ctx, int op, const float *a, const float *b, float *out, int32_t n)
+{
+	int rc = bind(ctx);
+	if (rc) return rc;
+	DevBuf da, db, dout;
+	size_t bytes = (size_t)n * sizeof(float);
+	rc = da.upload(a, bytes); if (rc) return rc;
+	if (b) { rc = db.upload(b, bytes); if (rc) { da.release(); return rc; } }
+	rc = dout.reserve(bytes);
+	if (!rc)
+	{
+		hipError_t e = wbrt_launch_math_probe(op, (const float *)da.p, b ? (const float *)db.p : nullptr, (float *)dout.p, n, ctx->stream);
+		if (e == hipSuccess) e = hipMemcpyAsync(out, dout.p, bytes, hipMemcpyDeviceToHost, ctx->stream);
+		if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+		if (e != hipSuccess) rc = fail(WBRT_ERR_HIP, hipGetErrorName(e));
+	}
+	da.release(); db.release(); dout.release();
+	return rc;
+}
+
+} // extern "C"

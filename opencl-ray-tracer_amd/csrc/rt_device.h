@@ -1,0 +1,74 @@
+// Internal interface between the C ABI (rt_capi.cpp) and the HIP kernels (rt_kernels.hip).
+#ifndef WBRT_RT_DEVICE_H
+#define WBRT_RT_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define WBRT_NUM_COUNTERS 26
+
+// Counter slots; same events and order as wbo_counters in the test oracle.
+enum
+{
+	C_PATHS = 0, C_SEGMENTS, C_RNG_DRAWS,
+	C_SPHERE_TESTS, C_SPHERE_DISC_GE0, C_SPHERE_SECOND_ROOT, C_SPHERE_ACCEPT,
+	C_BBOX_TESTS, C_BBOX_HITS,
+	C_TRI_TESTS, C_TRI_EXIT_PARALLEL, C_TRI_EXIT_U, C_TRI_EXIT_V, C_TRI_REACH_T, C_TRI_ACCEPT,
+	C_LAMBERT, C_METAL, C_METAL_FUZZ, C_DIELECTRIC, C_DIELECTRIC_DRAW, C_EMISSIVE,
+	C_SPHERE_TRIES, C_DISK_TRIES,
+	C_MISS, C_DEPTH_EXHAUSTED, C_ABSORBED
+};
+
+// Device-resident scene, repacked from the reference's AoS structs on upload.
+struct SceneDev
+{
+	// spheres, structure of arrays
+	const float4 *sph_geom;   // [S] center.x, center.y, center.z, radius*radius
+	const float  *sph_radius; // [S]
+	const float4 *sph_mat_a;  // [S] albedo.rgb, fuzz
+	const float2 *sph_mat_b;  // [S] ior, type (int bits)
+	int S;
+	// triangles grouped by bounding-box index (stable), 12 floats each:
+	//   p0.xyz e0.x | e0.yz e1.xy | e1.z 0 0 0     with e0 = p1-p0, e1 = p2-p0
+	const float4 *tri_geom;   // [3*T']
+	const float4 *tri_mat_a;  // [T'] albedo.rgb, fuzz
+	const float2 *tri_mat_b;  // [T'] ior, type
+	const int    *tri_orig;   // [T'] index in the caller's triangle array
+	int T;                    // T' = triangles whose boundingBoxId names an existing box
+	// bounding boxes
+	const float4 *box_min;    // [B] min.xyz, 0
+	const float4 *box_max;    // [B] max.xyz, 0
+	const int2   *box_range;  // [B] first, last+1 into the grouped triangle arrays
+	int B;
+	// sky: skyw*skyh texels + skyw+1 zero guard texels, 3 floats each
+	const float *sky;
+	int skyw, skyh;
+};
+
+struct RenderParams
+{
+	// camera (gpu_kernel.cl:53-69)
+	float org[3], hor[3], ver[3], llc[3], ddu[3], ddv[3];
+	float aperture;
+	int width, height, spp, max_depth;
+	// tiling: blocks of bsx*bsy pixels; this launch covers nbx*nby blocks whose block
+	// indices start at (off_bx, off_by)
+	int bsx, bsy, nbx, nby, off_bx, off_by;
+	// output: texel (row, col) relative to the first block lands at out[(row*out_w + col)*3]
+	int out_w;
+	int out_mode;
+	float *out;
+	int *ids;                       // primary-id launch only
+	unsigned long long *counters;   // counting launch only
+	const uint32_t *seeds;
+	SceneDev sc;
+};
+
+hipError_t wbrt_launch_render(const RenderParams &p, hipStream_t stream);
+hipError_t wbrt_launch_count(const RenderParams &p, hipStream_t stream);
+hipError_t wbrt_launch_ids(const RenderParams &p, hipStream_t stream);
+hipError_t wbrt_launch_tonemap(const float *image, float scale, int width, int height, uint8_t *rgb8, hipStream_t stream);
+// evaluates the device's float / double primitives on arrays (known-answer tests)
+hipError_t wbrt_launch_math_probe(int op, const float *a, const float *b, float *out, int n, hipStream_t stream);
+
+#endif

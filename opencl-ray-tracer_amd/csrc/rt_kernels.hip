@@ -1,0 +1,595 @@
+// HIP kernels of the path tracer for gfx950 (MI355X).  Compile with -ffp-contract=off:
+// every float result that can decide a hit or feed the image is produced by the same
+// IEEE binary32 operations, in the same order, as the reference kernel
+// (src/opencl/gpu_kernel.cl), so results match a non-contracting CPU build bit for bit.
+//
+// Design (not a translation of the reference's one-work-item-per-pixel nested loops):
+//   * one lane owns one pixel's random stream (the stream is sequential per pixel,
+//     gpu_kernel.cl:606), but the sample loop and the bounce loop are flattened into ONE
+//     loop whose body is "one ray segment": lanes whose path ended accumulate, regenerate
+//     the next camera ray of the same stream in place and rejoin, so the intersection
+//     phase always runs with every live lane of the wave;
+//   * the closest hit is kept as (t, primitive id); hit point, normal and material are
+//     derived once per segment for the winner only;
+//   * primitives are repacked on upload (SceneDev): sphere centre + radius^2, triangle
+//     p0 + precomputed edges, triangles grouped per bounding box.
+#include "rt_device.h"
+
+#include <math.h>
+
+namespace {
+
+struct F3 { float x, y, z; };
+
+__device__ __forceinline__ F3 f3(float x, float y, float z) { F3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ F3 operator+(F3 a, F3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ F3 operator-(F3 a, F3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ F3 operator*(F3 a, F3 b) { return f3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ F3 operator*(F3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ F3 operator/(F3 a, float s) { return f3(a.x / s, a.y / s, a.z / s); }
+// (x*x' + y*y') + z*z'  (gpu_kernel.cl:153-166)
+__device__ __forceinline__ float dot(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ F3 cross(F3 a, F3 b)
+{
+	return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ F3 unit(F3 a) { return a / sqrtf(dot(a, a)); }
+__device__ __forceinline__ F3 ld3(const float *p) { return f3(p[0], p[1], p[2]); }
+
+// ---------------------------------------------------------------- counters
+template <bool ON> struct Counters;
+template <> struct Counters<false>
+{
+	__device__ __forceinline__ void add(int, unsigned) {}
+	__device__ __forceinline__ void flush(unsigned long long *) {}
+};
+template <> struct Counters<true>
+{
+	unsigned v[WBRT_NUM_COUNTERS];
+	unsigned long long tot[WBRT_NUM_COUNTERS];
+	__device__ Counters()
+	{
+		for (int i = 0; i < WBRT_NUM_COUNTERS; ++i) { v[i] = 0; tot[i] = 0; }
+	}
+	__device__ __forceinline__ void add(int slot, unsigned n)
+	{
+		v[slot] += n;
+		if (v[slot] > 0x7fffffffu) { tot[slot] += v[slot]; v[slot] = 0; }
+	}
+	__device__ void flush(unsigned long long *g)
+	{
+		for (int i = 0; i < WBRT_NUM_COUNTERS; ++i)
+		{
+			unsigned long long x = tot[i] + v[i];
+			if (x) atomicAdd(&g[i], x);
+		}
+	}
+};
+
+// --------------------------------------------------------------------- RNG
+// gpu_kernel.cl:582-591: 48-bit LCG; float = (s >> 16) converted with round-to-nearest,
+// divided by 2^32 (an exact scaling).
+struct Rng
+{
+	unsigned long long s;
+	__device__ __forceinline__ float next()
+	{
+		s = (s * 0x5DEECE66DULL + 0xBULL) & 0xFFFFFFFFFFFFULL;
+		return (float)(unsigned)(s >> 16) * 2.3283064365386963e-10f;
+	}
+};
+
+// ---------------------------------------------- portable transcendental math
+// atan2 / asin / x^5 as fixed double-precision sequences of + - * / sqrt (no contraction).
+// OpenCL leaves the last bits of these builtins to the implementation; this sequence is
+// evaluated identically on the host, so a sky texel index never depends on the device.
+__device__ const double ATAN_K8[9] = {
+	0x0.0p+0,             0x1.fd5ba9aac2f6ep-4, 0x1.f5b75f92c80ddp-3,
+	0x1.6f61941e4def1p-2, 0x1.dac670561bb4fp-2, 0x1.1e00babdefeb4p-1,
+	0x1.4978fa3269ee1p-1, 0x1.700a7c5784634p-1, 0x1.921fb54442d18p-1
+};
+#define PT_PI   0x1.921fb54442d18p+1
+#define PT_PI_2 0x1.921fb54442d18p+0
+
+__device__ __noinline__ double atan2_core(double y, double x)
+{
+	if (x != x || y != y) return x + y;
+	double ax = fabs(x), ay = fabs(y);
+	double hi = ax > ay ? ax : ay;
+	double lo = ax > ay ? ay : ax;
+	double a = 0.0;
+	if (hi > 0.0)
+	{
+		if (hi == (double)INFINITY) a = (lo == (double)INFINITY) ? 1.0 : 0.0;
+		else a = lo / hi;
+	}
+	int k = (int)(a * 8.0 + 0.5);
+	double c = (double)k * 0.125;
+	double t = (a - c) / (1.0 + a * c);
+	double t2 = t * t;
+	double p = t2 * (1.0 / 9.0);
+	p = t2 * (p - 1.0 / 7.0);
+	p = t2 * (p + 1.0 / 5.0);
+	p = t2 * (p - 1.0 / 3.0);
+	p = t + t * p;
+	double r = ATAN_K8[k] + p;
+	if (ay > ax) r = PT_PI_2 - r;
+	if (__builtin_signbit(x)) r = PT_PI - r;
+	if (__builtin_signbit(y)) r = -r;
+	return r;
+}
+
+__device__ __forceinline__ float pt_atan2f(float y, float x) { return (float)atan2_core((double)y, (double)x); }
+
+__device__ __forceinline__ float pt_asinf(float y)
+{
+	double d = (double)y;
+	if (!(fabs(d) <= 1.0)) return NAN;
+	double c = sqrt((1.0 - d) * (1.0 + d));
+	return (float)atan2_core(d, c);
+}
+
+__device__ __forceinline__ float pt_pow5f(float x)
+{
+	double d = (double)x;
+	double d2 = d * d;
+	double d4 = d2 * d2;
+	return (float)(d4 * d);
+}
+
+// gpu_kernel.cl:234-241 and :342-347.  Non-finite coordinates fall back to texel 0
+// (the reference would read out of bounds).
+__device__ __forceinline__ F3 sky_lookup(const SceneDev &sc, F3 dir)
+{
+	F3 n = unit(dir);
+	float u = 0.5f + pt_atan2f(n.z, n.x) / (2.0f * 3.14159274101257324f);
+	float v = 0.5f - pt_asinf(n.y) / 3.14159274101257324f;
+	float fx = u * (float)sc.skyw;
+	float fy = v * (float)sc.skyh;
+	int x = (fx >= 0.0f && fx <= (float)sc.skyw) ? (int)fx : 0;
+	int y = (fy >= 0.0f && fy <= (float)sc.skyh) ? (int)fy : 0;
+	return ld3(sc.sky + 3 * (size_t)(y * sc.skyw + x));
+}
+
+// ------------------------------------------------------------ intersection
+// gpu_kernel.cl:358-394 + :455-478 + :489-520 + :534-555.  Returns the primitive id
+// (sphere index, S + grouped triangle index, -1) and the accepted t.
+template <bool STATS>
+__device__ __forceinline__ int closest_hit(const SceneDev &sc, F3 o, F3 d, float &t_out, Counters<STATS> &ctr)
+{
+	const float tmin = 0.001f;
+	float closest = INFINITY;
+	int id = -1;
+	const float a = dot(d, d);
+	if (STATS) ctr.add(C_SPHERE_TESTS, (unsigned)sc.S);
+	for (int i = 0; i < sc.S; ++i)
+	{
+		const float4 g = sc.sph_geom[i];
+		F3 oc = o - f3(g.x, g.y, g.z);
+		float hb = dot(oc, d);
+		float cc = dot(oc, oc) - g.w;
+		float disc = hb * hb - a * cc;
+		if (disc < 0) continue;
+		if (STATS) ctr.add(C_SPHERE_DISC_GE0, 1);
+		float sq = sqrtf(disc);
+		float root = (-hb - sq) / a;
+		if (root < tmin || closest < root)
+		{
+			if (STATS) ctr.add(C_SPHERE_SECOND_ROOT, 1);
+			root = (-hb + sq) / a;
+			if (root < tmin || closest < root) continue;
+		}
+		if (STATS) ctr.add(C_SPHERE_ACCEPT, 1);
+		closest = root;
+		id = i;
+	}
+	if (sc.B > 0)
+	{
+		if (STATS) ctr.add(C_BBOX_TESTS, (unsigned)sc.B);
+		const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+		for (int b = 0; b < sc.B; ++b)
+		{
+			const float4 mn = sc.box_min[b], mx = sc.box_max[b];
+			float tx1 = (mn.x - o.x) * ix, tx2 = (mx.x - o.x) * ix;
+			float lo = fminf(tx1, tx2), hi = fmaxf(tx1, tx2);
+			float ty1 = (mn.y - o.y) * iy, ty2 = (mx.y - o.y) * iy;
+			lo = fmaxf(lo, fminf(ty1, ty2));
+			hi = fminf(hi, fmaxf(ty1, ty2));
+			float tz1 = (mn.z - o.z) * iz, tz2 = (mx.z - o.z) * iz;
+			lo = fmaxf(lo, fminf(tz1, tz2));
+			hi = fminf(hi, fmaxf(tz1, tz2));
+			if (!(hi > fmaxf(lo, 0.0f))) continue;
+			if (STATS) ctr.add(C_BBOX_HITS, 1);
+			const int2 range = sc.box_range[b];
+			for (int j = range.x; j < range.y; ++j)
+			{
+				const float4 g0 = sc.tri_geom[3 * j + 0];
+				const float4 g1 = sc.tri_geom[3 * j + 1];
+				const float4 g2 = sc.tri_geom[3 * j + 2];
+				const F3 p0 = f3(g0.x, g0.y, g0.z), e0 = f3(g0.w, g1.x, g1.y), e1 = f3(g1.z, g1.w, g2.x);
+				if (STATS) ctr.add(C_TRI_TESTS, 1);
+				F3 h = cross(d, e1);
+				float det = dot(e0, h);
+				if (det > -0.00001f && det < 0.00001f) { if (STATS) ctr.add(C_TRI_EXIT_PARALLEL, 1); continue; }
+				float f = 1.0f / det;
+				F3 s = o - p0;
+				float u = f * dot(s, h);
+				if (u < 0.0f || u > 1.0f) { if (STATS) ctr.add(C_TRI_EXIT_U, 1); continue; }
+				F3 q = cross(s, e0);
+				float v = f * dot(d, q);
+				if (v < 0.0f || u + v > 1.0f) { if (STATS) ctr.add(C_TRI_EXIT_V, 1); continue; }
+				if (STATS) ctr.add(C_TRI_REACH_T, 1);
+				float t0 = f * dot(e1, q);
+				if (t0 > tmin && t0 < closest)
+				{
+					if (STATS) ctr.add(C_TRI_ACCEPT, 1);
+					closest = t0;
+					id = sc.S + j;
+				}
+			}
+		}
+	}
+	t_out = closest;
+	return id;
+}
+
+// gpu_kernel.cl:182-196
+template <bool STATS>
+__device__ __forceinline__ F3 rand_in_unit_sphere(Rng &rng, Counters<STATS> &ctr)
+{
+	for (;;)
+	{
+		if (STATS) { ctr.add(C_SPHERE_TRIES, 1); ctr.add(C_RNG_DRAWS, 3); }
+		float x = rng.next() * 2.0f - 1.0f;
+		float y = rng.next() * 2.0f - 1.0f;
+		float z = rng.next() * 2.0f - 1.0f;
+		F3 p = f3(x, y, z);
+		if (dot(p, p) >= 1.0f) continue;
+		return p;
+	}
+}
+
+// gpu_kernel.cl:209-212
+__device__ __forceinline__ F3 reflect(F3 v, F3 n) { return v - n * (2.0f * dot(v, n)); }
+
+// Pixel-stream state of one lane.
+struct Lane
+{
+	F3 o, d;        // current ray (direction not normalised, gpu_kernel.cl:575)
+	F3 thr;         // throughput
+	F3 sum;         // clamped per-sample sum
+	Rng rng;
+	float base_u, base_v; // in-block column/row + block origin (gpu_kernel.cl:626-627)
+	int depth, sample;
+};
+
+// gpu_kernel.cl:626-629 + :559-578: next camera ray of this lane's stream
+template <bool STATS>
+__device__ __forceinline__ void camera_ray(const RenderParams &p, Lane &L, Counters<STATS> &ctr)
+{
+	if (STATS) { ctr.add(C_PATHS, 1); ctr.add(C_RNG_DRAWS, 2); }
+	float u = (L.base_u + L.rng.next()) / (float)p.width;
+	float v = (L.base_v + L.rng.next()) / (float)p.height;
+	F3 org = ld3(p.org);
+	if (!(p.aperture <= 0))
+	{
+		float dx, dy;
+		for (;;) // gpu_kernel.cl:243-257
+		{
+			if (STATS) { ctr.add(C_DISK_TRIES, 1); ctr.add(C_RNG_DRAWS, 2); }
+			dx = L.rng.next() * 2.0f - 1.0f;
+			dy = L.rng.next() * 2.0f - 1.0f;
+			if (dx * dx + dy * dy + 0.0f * 0.0f >= 1.0f) continue;
+			break;
+		}
+		org = org + (ld3(p.ddu) * dx + ld3(p.ddv) * dy);
+	}
+	L.d = (ld3(p.llc) + (ld3(p.hor) * u + ld3(p.ver) * v)) - org;
+	L.o = org;
+	L.thr = f3(1.0f, 1.0f, 1.0f);
+	L.depth = 0;
+}
+
+// Maps a launch-wide work index to (block, in-block id).  Inside a block, lanes of a wave
+// cover an 8x8 pixel tile when the block size allows it (neighbouring pixels follow similar
+// paths); any bijection is valid because seeds and outputs are addressed by the in-block id.
+__device__ __forceinline__ bool locate(const RenderParams &p, long long w, int &gid, int &bx, int &by)
+{
+	const int block_px = p.bsx * p.bsy;
+	const long long total = (long long)block_px * p.nbx * p.nby;
+	if (w >= total) return false;
+	int blk = (int)(w / block_px);
+	int local = (int)(w - (long long)blk * block_px);
+	bx = blk % p.nbx;
+	by = blk / p.nbx;
+	if (((p.bsx | p.bsy) & 7) == 0)
+	{
+		int tile = local >> 6, l = local & 63;
+		int tpr = p.bsx >> 3;
+		int px = (tile % tpr) * 8 + (l & 7);
+		int py = (tile / tpr) * 8 + (l >> 3);
+		gid = py * p.bsx + px;
+	}
+	else gid = local;
+	return true;
+}
+
+__device__ __forceinline__ void init_lane(const RenderParams &p, Lane &L, int gid, int bx, int by)
+{
+	L.rng.s = (unsigned long long)p.seeds[gid];
+	L.base_u = (float)(gid % p.bsx) + ((float)p.bsx * (float)(bx + p.off_bx));
+	L.base_v = (float)(gid / p.bsx) + ((float)p.bsy * (float)(by + p.off_by));
+	L.sum = f3(0.0f, 0.0f, 0.0f);
+	L.sample = 0;
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(256) void k_render(const RenderParams p)
+{
+	Counters<STATS> ctr;
+	const SceneDev &sc = p.sc;
+	long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	int gid = 0, bx = 0, by = 0;
+	bool alive = locate(p, w, gid, bx, by);
+	Lane L;
+	L.o = L.d = L.thr = L.sum = f3(0, 0, 0);
+	L.rng.s = 0; L.base_u = L.base_v = 0; L.depth = 0; L.sample = 0;
+	if (alive)
+	{
+		init_lane(p, L, gid, bx, by);
+		alive = p.spp > 0;
+		if (alive) camera_ray<STATS>(p, L, ctr);
+	}
+
+	while (alive) // lanes of a wave leave together only when all are done; others idle
+	{
+		// 0 = path continues, 1 = ended black, 2 = ended on the sky, 3 = ended with `col`
+		int outcome = 0;
+		F3 col = f3(0.0f, 0.0f, 0.0f);
+		if (L.depth >= p.max_depth) // gpu_kernel.cl:276,337-340
+		{
+			outcome = (L.depth == p.max_depth) ? 1 : 2;
+			if (STATS && outcome == 1) ctr.add(C_DEPTH_EXHAUSTED, 1);
+		}
+		else
+		{
+			float t;
+			if (STATS) ctr.add(C_SEGMENTS, 1);
+			int id = closest_hit<STATS>(sc, L.o, L.d, t, ctr);
+			if (id < 0) outcome = 2;
+			else
+			{
+				// winner's surface (gpu_kernel.cl:480-484, :522-526, :352-356)
+				F3 hp = L.o + L.d * t;
+				F3 outward;
+				float4 ma;
+				float2 mb;
+				if (id < sc.S)
+				{
+					const float4 g = sc.sph_geom[id];
+					outward = (hp - f3(g.x, g.y, g.z)) / sc.sph_radius[id];
+					ma = sc.sph_mat_a[id];
+					mb = sc.sph_mat_b[id];
+				}
+				else
+				{
+					const int j = id - sc.S;
+					const float4 g0 = sc.tri_geom[3 * j + 0];
+					const float4 g1 = sc.tri_geom[3 * j + 1];
+					const float4 g2 = sc.tri_geom[3 * j + 2];
+					outward = unit(cross(f3(g0.w, g1.x, g1.y), f3(g1.z, g1.w, g2.x)));
+					ma = sc.tri_mat_a[j];
+					mb = sc.tri_mat_b[j];
+				}
+				const bool front = dot(L.d, outward) < 0;
+				const F3 n = front ? outward : outward * -1.0f;
+				const F3 albedo = f3(ma.x, ma.y, ma.z);
+				const float fuzz = ma.w, ior = mb.x;
+				const int type = __float_as_int(mb.y);
+				bool scattered = true;
+				F3 nd = L.d;
+				F3 att = f3(1.0f, 1.0f, 1.0f);
+				if (type == 0) // gpu_kernel.cl:398-413
+				{
+					if (STATS) ctr.add(C_LAMBERT, 1);
+					nd = n + unit(rand_in_unit_sphere<STATS>(L.rng, ctr));
+					const float eps = 1e-8f;
+					if (fabsf(nd.x) < eps && fabsf(nd.y) < eps && fabsf(nd.z) < eps) nd = n;
+					att = albedo;
+				}
+				else if (type == 1) // gpu_kernel.cl:415-423
+				{
+					if (STATS) ctr.add(C_METAL, 1);
+					nd = reflect(unit(L.d), n);
+					if (fuzz > 0.0f)
+					{
+						if (STATS) ctr.add(C_METAL_FUZZ, 1);
+						nd = nd + rand_in_unit_sphere<STATS>(L.rng, ctr) * fuzz;
+					}
+					att = albedo;
+					if (!(dot(nd, n) > 0))
+					{
+						if (STATS) ctr.add(C_ABSORBED, 1);
+						scattered = false;
+						outcome = 1;
+					}
+				}
+				else if (type == 2) // gpu_kernel.cl:425-451, :214-227
+				{
+					if (STATS) ctr.add(C_DIELECTRIC, 1);
+					const float ratio = front ? (1.0f / ior) : ior;
+					const F3 ud = unit(L.d);
+					const float cos_t = fminf(dot(ud * -1.0f, n), 1.0f);
+					const float sin_t = sqrtf(1.0f - cos_t * cos_t);
+					bool refl = ratio * sin_t > 1.0f;
+					if (!refl)
+					{
+						if (STATS) { ctr.add(C_DIELECTRIC_DRAW, 1); ctr.add(C_RNG_DRAWS, 1); }
+						float r0 = (1.0f - ratio) / (1.0f + ratio);
+						r0 = r0 * r0;
+						const float fr = r0 + (1.0f - r0) * pt_pow5f(1.0f - cos_t);
+						refl = fr > L.rng.next();
+					}
+					if (refl) nd = reflect(ud, n);
+					else
+					{
+						const float c2 = fminf(dot(ud * -1.0f, n), 1.0f);
+						const F3 perp = ud * ratio + n * (c2 * ratio);
+						const F3 par = n * (-sqrtf(fabsf(1.0f - dot(perp, perp))));
+						nd = perp + par;
+					}
+				}
+				else if (type == 3) // gpu_kernel.cl:326-329
+				{
+					if (STATS) ctr.add(C_EMISSIVE, 1);
+					scattered = false;
+					outcome = 3;
+					col = L.thr * albedo;
+				}
+				else
+				{
+					// unknown material: depth advances, same ray again (gpu_kernel.cl:331-332)
+					scattered = false;
+					L.depth++;
+				}
+				if (scattered)
+				{
+					L.o = hp;
+					L.d = nd;
+					L.thr = L.thr * att;
+					L.depth++;
+				}
+			}
+		}
+
+		if (outcome == 2)
+		{
+			if (STATS) ctr.add(C_MISS, 1);
+			col = L.thr * sky_lookup(sc, L.d);
+		}
+		if (outcome != 0)
+		{
+			// gpu_kernel.cl:632-644: clamp, NaN -> running sum, accumulate
+			if (col.x > 1.0f) col.x = 1.0f;
+			if (col.y > 1.0f) col.y = 1.0f;
+			if (col.z > 1.0f) col.z = 1.0f;
+			if (col.x < 0.0f) col.x = 0.0f;
+			if (col.y < 0.0f) col.y = 0.0f;
+			if (col.z < 0.0f) col.z = 0.0f;
+			if (col.x != col.x) col.x = L.sum.x;
+			if (col.y != col.y) col.y = L.sum.y;
+			if (col.z != col.z) col.z = L.sum.z;
+			L.sum = L.sum + col;
+			L.sample++;
+			if (L.sample < p.spp) camera_ray<STATS>(p, L, ctr);
+			else alive = false;
+		}
+	}
+
+	if (STATS)
+	{
+		ctr.flush(p.counters);
+		return;
+	}
+	if (w < (long long)p.bsx * p.bsy * p.nbx * p.nby)
+	{
+		const int row = gid / p.bsx + p.bsy * by, colx = gid % p.bsx + p.bsx * bx;
+		float *dst = p.out + 3 * ((size_t)row * p.out_w + colx);
+		F3 r = L.sum;
+		if (p.out_mode == 0) r = r / (float)p.spp; // gpu_kernel.cl:647
+		if (p.out_mode == 2) { r.x += dst[0]; r.y += dst[1]; r.z += dst[2]; }
+		dst[0] = r.x; dst[1] = r.y; dst[2] = r.z;
+	}
+}
+
+// Primary-hit primitive id of sample 0's first segment, in the caller's numbering.
+__global__ __launch_bounds__(256) void k_primary_ids(const RenderParams p)
+{
+	Counters<false> ctr;
+	long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	int gid, bx, by;
+	if (!locate(p, w, gid, bx, by)) return;
+	Lane L;
+	init_lane(p, L, gid, bx, by);
+	camera_ray<false>(p, L, ctr);
+	float t;
+	int id = closest_hit<false>(p.sc, L.o, L.d, t, ctr);
+	if (id >= p.sc.S) id = p.sc.S + p.sc.tri_orig[id - p.sc.S];
+	const int row = gid / p.bsx + p.bsy * by, colx = gid % p.bsx + p.bsx * bx;
+	p.ids[(size_t)row * p.out_w + colx] = id;
+}
+
+// colour.cpp:5-15 per channel; output rows top-down, R,G,B.
+__global__ void k_tonemap(const float *image, float scale, int width, int height, uint8_t *rgb8)
+{
+	const int n = width * height * 3;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+	{
+		const int row = i / (width * 3), rest = i - row * (width * 3);
+		const float c = image[(size_t)(height - 1 - row) * width * 3 + rest] * scale;
+		const float g = (float)(sqrt((double)c) * (double)255.0f);
+		rgb8[i] = (uint8_t)g;
+	}
+}
+
+// op: 0 a/b, 1 sqrtf(a), 2 atan2(a,b), 3 asin(a), 4 a^5, 5 rng float of seed bits a (32-bit) after b draws
+__global__ void k_math_probe(int op, const float *a, const float *b, float *out, int n)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	float x = a[i], y = b ? b[i] : 0.0f, r = 0.0f;
+	switch (op)
+	{
+	case 0: r = x / y; break;
+	case 1: r = sqrtf(x); break;
+	case 2: r = pt_atan2f(x, y); break;
+	case 3: r = pt_asinf(x); break;
+	case 4: r = pt_pow5f(x); break;
+	case 5:
+	{
+		Rng g; g.s = (unsigned long long)__float_as_uint(x);
+		int k = (int)__float_as_uint(y);
+		for (int j = 0; j < k; ++j) r = g.next();
+		break;
+	}
+	}
+	out[i] = r;
+}
+
+inline unsigned grid_for(const RenderParams &p)
+{
+	long long total = (long long)p.bsx * p.bsy * p.nbx * p.nby;
+	return (unsigned)((total + 255) / 256);
+}
+
+} // namespace
+
+hipError_t wbrt_launch_render(const RenderParams &p, hipStream_t stream)
+{
+	hipLaunchKernelGGL(k_render<false>, dim3(grid_for(p)), dim3(256), 0, stream, p);
+	return hipGetLastError();
+}
+
+hipError_t wbrt_launch_count(const RenderParams &p, hipStream_t stream)
+{
+	hipLaunchKernelGGL(k_render<true>, dim3(grid_for(p)), dim3(256), 0, stream, p);
+	return hipGetLastError();
+}
+
+hipError_t wbrt_launch_ids(const RenderParams &p, hipStream_t stream)
+{
+	hipLaunchKernelGGL(k_primary_ids, dim3(grid_for(p)), dim3(256), 0, stream, p);
+	return hipGetLastError();
+}
+
+hipError_t wbrt_launch_tonemap(const float *image, float scale, int width, int height, uint8_t *rgb8, hipStream_t stream)
+{
+	hipLaunchKernelGGL(k_tonemap, dim3(2048), dim3(256), 0, stream, image, scale, width, height, rgb8);
+	return hipGetLastError();
+}
+
+hipError_t wbrt_launch_math_probe(int op, const float *a, const float *b, float *out, int n, hipStream_t stream)
+{
+	hipLaunchKernelGGL(k_math_probe, dim3((n + 255) / 256), dim3(256), 0, stream, op, a, b, out, n);
+	return hipGetLastError();
+}
