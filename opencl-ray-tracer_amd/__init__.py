@@ -141,6 +141,15 @@ def lib():
             raise RuntimeError(
                 "%s is missing: build it first (python -c 'import __graft_entry__ as g; g.build()'); "
                 "there is no CPU fallback" % LIB_PATH)
+        # One HIP runtime per process: PyTorch's wheel bundles its own libamdhip64.so.7 and a
+        # second, separately initialised runtime in the same process finds no GPU.  Importing
+        # torch first makes the loader resolve this library's libamdhip64.so.7 dependency to
+        # the copy torch already loaded.  (A C++ host without torch uses /opt/rocm's.)
+        if os.environ.get("WBRT_SKIP_TORCH") != "1":
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(l, name)

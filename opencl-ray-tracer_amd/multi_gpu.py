@@ -1,0 +1,63 @@
+"""Samples-per-pixel sharding across GPUs (one process per GPU, torch.distributed / RCCL).
+
+The reference has one random stream per pixel and a data-dependent number of draws per
+sample (gpu_kernel.cl:606,624-645), so a frame is split into V *seed shards* instead of
+sample ranges: shard v is the reference kernel's semantics run with its own seed buffer
+(make_seeds(base, shard=v)) and spp_per_shard samples, producing the UN-NORMALISED clamped
+per-sample sum.  frame = sum_v shard_v / (V * spp_per_shard).  Rank r of K renders shards
+{v : v % K == r}, accumulating them on the device; one all-reduce(sum) of the
+width*height*3 float buffer per frame is the only exchange step; every rank then normalises
+and tone-maps (only rank 0 needs to keep the picture).
+
+torch is used for device memory, streams and the collective only; rendering goes through
+the C ABI (Context).
+"""
+from . import OUT_ACCUMULATE, OUT_SUM, make_seeds
+
+
+def shards_for_rank(num_shards, rank, world):
+    return [v for v in range(num_shards) if v % world == rank]
+
+
+class FrameBuffers:
+    """Device-resident accumulation buffer (float, row 0 = bottom) and 8-bit picture (row 0 = top)."""
+
+    def __init__(self, width, height, device):
+        import torch
+        self.width, self.height = width, height
+        self.accum = torch.zeros(height * width * 3, dtype=torch.float32, device=device)
+        self.rgb8 = torch.zeros(height * width * 3, dtype=torch.uint8, device=device)
+
+    def image(self):
+        return self.accum.view(self.height, self.width, 3)
+
+    def picture(self):
+        return self.rgb8.view(self.height, self.width, 3)
+
+
+def render_step(ctx, cam, frame, total_spp, stream=None, all_reduce=None):
+    """One frame with the seed shard currently uploaded in ctx: render the clamped sum into
+    frame.accum, all-reduce it over ranks when a collective is given, normalise by total_spp
+    and tone-map into frame.rgb8.  Everything is enqueued on `stream`."""
+    ctx.render_frame_device(cam, frame.accum.data_ptr(), OUT_SUM, stream)
+    if all_reduce is not None:
+        all_reduce(frame.accum)
+    ctx.tonemap_device(frame.accum.data_ptr(), 1.0 / float(total_spp), cam.width, cam.height,
+                       frame.rgb8.data_ptr(), stream)
+
+
+def render_sharded_frame(ctx, cam, frame, num_shards, base_seed, rank, world, stream=None, all_reduce=None):
+    """Strong-scaling form: a frame of num_shards seed shards (cam.samplesPerPixel samples each)
+    split over `world` ranks.  Returns the number of shards this rank rendered."""
+    bw, bh = int(cam.blockSize.x), int(cam.blockSize.y)
+    frame.accum.zero_()
+    mine = shards_for_rank(num_shards, rank, world)
+    for v in mine:
+        ctx.synchronize()  # the previous launch must be done before its seed buffer is replaced
+        ctx.upload_seeds(make_seeds(bw * bh, base_seed, shard=v))
+        ctx.render_frame_device(cam, frame.accum.data_ptr(), OUT_ACCUMULATE, stream)
+    if all_reduce is not None:
+        all_reduce(frame.accum)
+    ctx.tonemap_device(frame.accum.data_ptr(), 1.0 / float(num_shards * cam.samplesPerPixel), cam.width, cam.height,
+                       frame.rgb8.data_ptr(), stream)
+    return len(mine)

@@ -1,0 +1,212 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the oracle and the
+golden vectors.  Bar: bit-exact primary-hit ids; images bit-exact against the oracle in its
+portable-math mode and within MAE <= 1e-3 / PSNR >= 40 dB of the reference's golden images
+(they differ only where atan2/asin last bits flip a sky texel)."""
+import numpy as np
+import pytest
+
+from util import pkg, orc, golden, golden_meta, scene_by_tag, camera_by_meta, bits, image_error
+
+pytestmark = pytest.mark.gpu
+
+ol = orc.oracle_lib()
+
+
+def _setup(ctx, scene, cam, blocks, seed):
+    bw, bh = pkg.set_blocks(cam, blocks)
+    seeds = pkg.make_seeds(bw * bh, seed)
+    ctx.upload_scene(scene)
+    ctx.upload_seeds(seeds)
+    return seeds
+
+
+def test_device_float_primitives_are_ieee(gpu_ctx):
+    rs = np.random.RandomState(1)
+    n = 1 << 16
+    a = (rs.standard_normal(n) * 10 ** rs.uniform(-18, 18, n)).astype(np.float32)
+    b = (rs.standard_normal(n) * 10 ** rs.uniform(-18, 18, n)).astype(np.float32)
+    with np.errstate(all="ignore"):
+        assert np.array_equal(bits(gpu_ctx.math_probe(0, a, b)), bits(a / b))
+        assert np.array_equal(bits(gpu_ctx.math_probe(1, np.abs(a))), bits(np.sqrt(np.abs(a))))
+    y, x = a[:8192], b[:8192]
+    want = np.array([ol.wbo_atan2f_portable(float(p), float(q)) for p, q in zip(y, x)], dtype=np.float32)
+    assert np.array_equal(bits(gpu_ctx.math_probe(2, y, x)), bits(want))
+    u = rs.uniform(-1, 1, 8192).astype(np.float32)
+    u[:4] = [1.0, -1.0, 0.0, -0.0]
+    want = np.array([ol.wbo_asinf_portable(float(p)) for p in u], dtype=np.float32)
+    assert np.array_equal(bits(gpu_ctx.math_probe(3, u)), bits(want))
+    want = np.array([ol.wbo_pow5f_portable(float(p)) for p in u], dtype=np.float32)
+    assert np.array_equal(bits(gpu_ctx.math_probe(4, u)), bits(want))
+
+
+def test_device_rng_matches_golden(gpu_ctx):
+    z = golden("rng_kat.npz")
+    seeds = z["seeds"].astype(np.uint32)  # the kernel seeds are 32-bit (gpu_kernel.cl:598,606)
+    keep = z["seeds"] < 2 ** 32
+    for k in (1, 3, 8):
+        got = gpu_ctx.math_probe(5, seeds.view(np.float32), np.full(len(seeds), k, dtype=np.uint32).view(np.float32))
+        assert np.array_equal(bits(got)[keep], bits(z["floats"][:, k - 1])[keep])
+
+
+IMAGE_CASES = ["readme_160x90_s8_b4", "readme_160x90_s8_b1", "readme_64x36_s250_b4",
+               "maincpp_160x90_s8_b4", "maincpp_f1car_96x54_s2_b4"]
+
+
+@pytest.mark.parametrize("tag", IMAGE_CASES)
+def test_golden_cases(gpu_ctx, tag):
+    z = golden("img_%s.npz" % tag)
+    meta = golden_meta(z)
+    scene = scene_by_tag(tag)
+    cam = camera_by_meta(meta)
+    seeds = _setup(gpu_ctx, scene, cam, meta["blocks"], meta["seed"])
+    img = gpu_ctx.render_frame(cam)
+    ids = gpu_ctx.primary_ids(cam)
+    # reference golden: ids bit-exact, image within the stated tolerance
+    assert np.array_equal(ids, z["ids"])
+    mae, psnr = image_error(img, z["image"])
+    assert mae <= 1e-3 and psnr >= 40.0, (mae, psnr)
+    # oracle (portable math): bit-exact image
+    O = orc.Oracle(scene)
+    assert np.array_equal(bits(img), bits(O.render_frame(cam, seeds)))
+
+
+@pytest.mark.parametrize("case", [
+    ("readme", 320, 16, 4, 7), ("readme", 200, 5, 1, 8), ("readme", 328, 3, 4, 9),
+    ("maincpp", 320, 16, 4, 5), ("stress", 128, 4, 4, 3), ("stress", 96, 3, 1, 4),
+])
+def test_against_oracle_bitwise(gpu_ctx, case):
+    name, width, spp, blocks, seed = case
+    if name == "readme":
+        scene, cam = pkg.scene_readme(), pkg.camera_readme(width, spp, 50)
+    elif name == "maincpp":
+        scene, cam = pkg.scene_main_cpp(), pkg.camera_main_cpp(width, spp, 50)
+    else:
+        scene, cam = pkg.scene_stress(40, 24, 24, 4, 4), pkg.camera_stress(width, spp, 50)
+    seeds = _setup(gpu_ctx, scene, cam, blocks, seed)
+    O = orc.Oracle(scene)
+    img = gpu_ctx.render_frame(cam)
+    assert np.array_equal(bits(img), bits(O.render_frame(cam, seeds)))
+    assert np.array_equal(gpu_ctx.primary_ids(cam), O.primary_ids(cam, seeds))
+    # identical control flow: every event counter equal
+    _, oc = O.render_frame(cam, seeds, counters=True)
+    gc = gpu_ctx.count_events(cam)
+    assert gc == dict(zip(pkg.COUNTER_NAMES, map(int, oc)))
+
+
+def test_block_entry_point_equals_frame_region(gpu_ctx):
+    scene, cam = pkg.scene_readme(), pkg.camera_readme(160, 4, 50)
+    _setup(gpu_ctx, scene, cam, 4, 12)
+    bw, bh = int(cam.blockSize.x), int(cam.blockSize.y)
+    frame = gpu_ctx.render_frame(cam)
+    for by in range(cam.height // bh):
+        for bx in range(cam.width // bw):
+            c = cam.copy()
+            c.blockOffset = pkg.vec3(bx, by, 0)
+            blk = gpu_ctx.render_block(c)
+            assert np.array_equal(bits(blk), bits(frame[by * bh:(by + 1) * bh, bx * bw:(bx + 1) * bw]))
+
+
+def test_output_modes_and_shard_sum(gpu_ctx):
+    """Samples-per-pixel shards: frame = sum over shards of clamped sums / spp."""
+    scene, cam = pkg.scene_readme(), pkg.camera_readme(160, 6, 50)
+    bw, bh = pkg.set_blocks(cam, 4)
+    gpu_ctx.upload_scene(scene)
+    shards = [pkg.make_seeds(bw * bh, 99, shard=v) for v in range(3)]
+    sums = []
+    acc = np.zeros((cam.height, cam.width, 3), dtype=np.float32)
+    O = orc.Oracle(scene)
+    for s in shards:
+        gpu_ctx.upload_seeds(s)
+        one = gpu_ctx.render_frame(cam, pkg.OUT_SUM)
+        assert np.array_equal(bits(one), bits(O.render_frame(cam, s, out_mode=orc.OUT_SUM)))
+        mean = gpu_ctx.render_frame(cam, pkg.OUT_MEAN)
+        assert np.array_equal(bits(mean), bits(one / np.float32(cam.samplesPerPixel)))
+        sums.append(one)
+        gpu_ctx.render_frame(cam, pkg.OUT_ACCUMULATE, into=acc)
+    assert np.array_equal(bits(acc), bits((sums[0] + sums[1]) + sums[2]))
+
+
+def test_tonemap_device_equals_host(gpu_ctx):
+    import torch
+    scene, cam = pkg.scene_readme(), pkg.camera_readme(160, 4, 50)
+    _setup(gpu_ctx, scene, cam, 4, 12)
+    img = gpu_ctx.render_frame(cam)
+    d_img = torch.from_numpy(img).to("cuda:0")
+    d_out = torch.zeros(cam.height * cam.width * 3, dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    gpu_ctx.tonemap_device(d_img.data_ptr(), 1.0, cam.width, cam.height, d_out.data_ptr())
+    gpu_ctx.synchronize()
+    got = d_out.cpu().numpy().reshape(cam.height, cam.width, 3)
+    assert np.array_equal(got, pkg.tonemap_host(img))
+
+
+def test_edge_cases(gpu_ctx):
+    scene = pkg.scene_readme()
+    seeds = pkg.make_seeds(16 * 9, 1)
+    gpu_ctx.upload_scene(scene)
+    gpu_ctx.upload_seeds(seeds)
+    cam = pkg.camera_readme(16, 0, 50)
+    pkg.set_blocks(cam, 1)
+    assert np.isnan(gpu_ctx.render_frame(cam)).all()          # 0 spp: 0/0
+    cam = pkg.camera_readme(16, 2, 0)
+    pkg.set_blocks(cam, 1)
+    assert not gpu_ctx.render_frame(cam).any()                # depth 0: black
+    empty = pkg.Scene()
+    gpu_ctx.upload_scene(empty)
+    cam = pkg.camera_readme(16, 2, 5)
+    pkg.set_blocks(cam, 1)
+    img = gpu_ctx.render_frame(cam)
+    assert np.array_equal(bits(img), bits(orc.Oracle(empty).render_frame(cam, seeds)))
+    assert (gpu_ctx.primary_ids(cam) == -1).all()
+    # triangles that name no existing box are never tested (gpu_kernel.cl:374-380)
+    sc = pkg.scene_stress(10, 8, 8, 2, 2)
+    for i in range(0, sc.T, 3):
+        sc.triangles[i].boundingBoxId = 77
+    cam = pkg.camera_stress(64, 2, 8)
+    seeds = _setup(gpu_ctx, sc, cam, 1, 5)
+    assert np.array_equal(bits(gpu_ctx.render_frame(cam)), bits(orc.Oracle(sc).render_frame(cam, seeds)))
+    assert np.array_equal(gpu_ctx.primary_ids(cam), orc.Oracle(sc).primary_ids(cam, seeds))
+
+
+def test_errors_are_reported(gpu_ctx):
+    ctx = pkg.Context(0)
+    cam = pkg.camera_readme(64, 1, 5)
+    with pytest.raises(pkg.WbrtError):
+        ctx.render_frame(cam)                                   # nothing uploaded
+    ctx.upload_scene(pkg.scene_readme())
+    ctx.upload_seeds(pkg.make_seeds(10, 1))
+    with pytest.raises(pkg.WbrtError):
+        ctx.render_frame(cam)                                   # seed buffer smaller than a block
+    cam.blockSize = pkg.vec3(60, 36, 0)
+    ctx.upload_seeds(pkg.make_seeds(64 * 36, 1))
+    with pytest.raises(pkg.WbrtError):
+        ctx.render_frame(cam)                                   # block does not divide the image
+    with pytest.raises(pkg.WbrtError):
+        pkg.Context(4096)
+    ctx.close()
+
+
+def test_headline_config_full_size(gpu_ctx):
+    """1280x720, 250 spp, depth 50, 4 blocks: golden primary ids bit-exact; image properties
+    that hold at any size (determinism, shard decomposition, block == frame region)."""
+    z = golden("ids_readme_1280x720_b4.npz")
+    scene, cam = pkg.scene_readme(), pkg.camera_readme(1280, 250, 50)
+    seeds = _setup(gpu_ctx, scene, cam, 4, int(z["seed"][0]))
+    assert np.array_equal(gpu_ctx.primary_ids(cam), z["ids"].astype(np.int32))
+    a = gpu_ctx.render_frame(cam)
+    b = gpu_ctx.render_frame(cam)
+    assert np.array_equal(bits(a), bits(b))
+    assert np.isfinite(a).all() and a.min() >= 0.0 and a.max() <= 1.0
+    c = cam.copy()
+    c.blockOffset = pkg.vec3(1, 0, 0)
+    blk = gpu_ctx.render_block(c)
+    assert np.array_equal(bits(blk), bits(a[0:360, 640:1280]))
+    # a 64-pixel-wide strip of the same frame against the oracle, bit for bit
+    O = orc.Oracle(scene)
+    strip = cam.copy()
+    strip.blockSize = pkg.vec3(64, 8, 0)
+    gpu_ctx.upload_seeds(seeds[: 64 * 8])
+    strip.blockOffset = pkg.vec3(9, 40, 0)
+    got = gpu_ctx.render_block(strip)
+    want = O.render_block(strip, seeds[: 64 * 8])
+    assert np.array_equal(bits(got), bits(want))

@@ -1,0 +1,177 @@
+"""CPU tests of the C ABI's host half: the library loads and exports every declared symbol,
+and the host helpers (camera, block planner, seeds, tone map, writers, loaders) behave as
+the reference's host functions do."""
+import os
+import re
+import struct
+
+import numpy as np
+
+from util import pkg, ROOT, golden
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "ocl_rt_amd.h")).read()
+    declared = sorted(set(re.findall(r"\b(wbrt_[a-z0-9_]+)\s*\(", header)))
+    assert declared == pkg.EXPORTED_SYMBOLS
+    lib = pkg.lib()
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert os.path.dirname(pkg.LIB_PATH).endswith("opencl-ray-tracer_amd")
+
+
+def test_image_height_and_block_planner():
+    # globals.hpp:8-10 and utility.cpp:192-236 (values checked against the reference's rule by hand)
+    assert [pkg.image_height(w) for w in (1280, 1920, 3840, 64)] == [720, 1080, 2160, 36]
+    assert pkg.ideal_block_size(1280, 720, 4) == (640, 360)
+    assert pkg.ideal_block_size(1920, 1080, 4) == (960, 540)
+    assert pkg.ideal_block_size(3840, 2160, 4) == (1920, 1080)
+    assert pkg.ideal_block_size(1280, 720, 1) == (1280, 720)
+    # largest product <= ceil(pixels/target) wins, ties go to the most square pair
+    bw, bh = pkg.ideal_block_size(1280, 720, 3)
+    assert 1280 % bw == 0 and 720 % bh == 0 and bw * bh <= -(-1280 * 720 // 3)
+    best = max(fw * fh for fw in range(1, 1281) if 1280 % fw == 0 for fh in range(1, 721)
+               if 720 % fh == 0 and fw * fh <= -(-1280 * 720 // 3))
+    assert bw * bh == best
+
+
+def test_camera_readme_values():
+    cam = pkg.camera_readme(1280, 250, 50)
+    assert (cam.width, cam.height, cam.samplesPerPixel, cam.maxDepth) == (1280, 720, 250, 50)
+    assert cam.origin.tuple() == (0.0, 0.0, 0.0)
+    # fov 90, focus 1: viewport height 2*tan(pi/4) ~ 2, width = 1.7777777*height
+    assert abs(cam.vertical.y - 2.0) < 1e-6 and abs(cam.horizontal.x - 2.0 * 1.7777777) < 1e-5
+    assert abs(cam.lowerLeftCorner.x + 1.7777777) < 1e-5 and abs(cam.lowerLeftCorner.y + 1.0) < 1e-6
+    assert abs(cam.lowerLeftCorner.z + 1.0) < 1e-7
+    assert cam.aperture == 0.0
+    m = pkg.camera_main_cpp(1280, 5, 32)
+    # aperture is converted from degrees to radians and kept in the struct (cl_camera.cpp:6,44)
+    assert abs(m.aperture - 1.2 * np.float32(3.141592654) / 180.0) < 1e-8
+    assert m.focusDistance == 2.0
+    u = np.array(m.horizontal.tuple())
+    v = np.array(m.vertical.tuple())
+    assert abs(np.dot(u, v)) < 1e-5
+    d = np.array(m.defocusDiscU.tuple())
+    assert abs(np.linalg.norm(d) - 2.0 * np.tan(m.aperture / 2)) < 1e-6
+
+
+def test_seeds_are_deterministic_and_sharded():
+    a = pkg.make_seeds(1000, 5, 0)
+    assert np.array_equal(a, pkg.make_seeds(1000, 5, 0))
+    assert not np.array_equal(a, pkg.make_seeds(1000, 5, 1))
+    assert not np.array_equal(a, pkg.make_seeds(1000, 6, 0))
+    assert np.array_equal(a[:10], pkg.make_seeds(10, 5, 0))
+    assert len(np.unique(a)) > 990
+
+
+def test_tonemap_and_writers(tmp_path):
+    img = np.zeros((2, 3, 3), dtype=np.float32)
+    img[0, 0] = [0.0, 0.25, 1.0]   # bottom-left pixel
+    img[1, 2] = [0.5, 0.81, 0.04]  # top-right pixel
+    rgb = pkg.tonemap_host(img)
+    assert rgb.shape == (2, 3, 3)
+    assert rgb[1, 0].tolist() == [0, 127, 255]           # bottom row comes last (top-down output)
+    assert rgb[0, 2].tolist() == [int(np.sqrt(0.5) * 255), 229, 51]
+    assert pkg.tonemap_host(img * 4, 0.25)[1, 0].tolist() == [0, 127, 255]
+    p = str(tmp_path / "a.ppm")
+    pkg.write_ppm(p, rgb)
+    data = open(p, "rb").read()
+    assert data.startswith(b"P6\n3 2\n255\n") and data[11:] == rgb.tobytes()
+    p = str(tmp_path / "a.pfm")
+    pkg.write_pfm(p, img)
+    data = open(p, "rb").read()
+    assert data.startswith(b"PF\n3 2\n-1.0\n") and data[len(b"PF\n3 2\n-1.0\n"):] == img.tobytes()
+    p = str(tmp_path / "a.bmp")
+    pkg.write_bmp(p, rgb)
+    data = open(p, "rb").read()
+    stride = 12  # 3 px * 3 B = 9, padded to 12
+    assert data[:2] == b"BM" and struct.unpack("<I", data[2:6])[0] == 54 + stride * 2 == len(data)
+    assert data[10] == 54 and data[14] == 40
+    assert struct.unpack("<ii", data[18:26]) == (3, 2) and data[26] == 1 and data[28] == 24
+    first_row = data[54:54 + 9]  # bottom row, B,G,R
+    assert list(first_row[:3]) == [255, 127, 0]
+
+
+def test_obj_loader(tmp_path):
+    obj = tmp_path / "m.obj"
+    obj.write_text("# test\no thing\nv 0 0 0\nv 1 0 0\nv 0 1 0\nv 0 0 -2.5\nvn 0 0 1\n"
+                   "s off\nf 1//1 2//1 3//1\nf 1/1/1 3/1/1 4/1/1\n")
+    mat = pkg.material((0.8, 0.6, 0.2), 0.5, 0.0, pkg.METAL)
+    tris, mn, mx, nv = pkg.read_mesh(str(obj), (2, 2, 2), (0.5, -1.0, -0.25), mat, 3)
+    assert nv == 4 and len(tris) == 2
+    assert tris[0].p1.tuple() == (2.5, -1.0, -0.25) and tris[0].p2.tuple() == (0.5, 1.0, -0.25)
+    assert tris[1].p2.tuple() == (0.5, -1.0, -5.25)
+    assert tris[1].boundingBoxId == 3 and tris[1].material.type == pkg.METAL and tris[1].material.fuzz == 0.5
+    assert mn.tuple() == (0.5, -1.0, -5.25)
+    # maximum starts at FLT_MIN (main.cpp:114-115): an all-negative axis keeps 1.17549435e-38
+    assert mx.x == 2.5 and mx.y == 1.0 and mx.z == np.float32(np.finfo(np.float32).tiny)
+
+
+def test_reference_mesh_fixture_bounds():
+    # the f1_car soup with main.cpp's transform reproduces the survey's bounding box
+    from util import scene_main_cpp_with_mesh
+    sc = scene_main_cpp_with_mesh("f1_car")
+    assert sc.T == 15329 and sc.B == 1 and sc.S == 8
+    b = sc.boxes[0]
+    assert np.allclose(b.min.tuple(), (-1.1281, -0.4965, -1.3759), atol=1e-4)
+    assert abs(b.max.x - 0.9657) < 1e-4 and b.max.y == b.max.z == np.float32(np.finfo(np.float32).tiny)
+    assert golden("meshes.npz")["burger"].shape == (828, 9)
+
+
+def _rgbe(rgb):
+    m = float(max(rgb))
+    if m < 1e-32:
+        return (0, 0, 0, 0)
+    e = int(np.floor(np.log2(m))) + 1
+    s = 256.0 / 2.0 ** e
+    return (int(rgb[0] * s), int(rgb[1] * s), int(rgb[2] * s), e + 128)
+
+
+def test_hdr_loader_and_sky_tonemap(tmp_path):
+    w, h = 16, 3
+    rs = np.random.RandomState(0)
+    px = rs.uniform(0, 4, (h, w, 3))
+    px[1, 3:12] = px[1, 3]  # a run
+    quads = np.array([[_rgbe(px[y, x]) for x in range(w)] for y in range(h)], dtype=np.uint8)
+    body = bytearray()
+    for y in range(h):
+        body += bytes([2, 2, (w >> 8) & 0xFF, w & 0xFF])
+        for comp in range(4):
+            row = quads[y, :, comp]
+            x = 0
+            while x < w:
+                run = 1
+                while x + run < w and run < 127 and row[x + run] == row[x]:
+                    run += 1
+                if run >= 3:
+                    body += bytes([128 + run, int(row[x])])
+                    x += run
+                else:
+                    lit = 1
+                    while x + lit < w and lit < 128 and not (x + lit + 2 < w and row[x + lit] == row[x + lit + 1] == row[x + lit + 2]):
+                        lit += 1
+                    body += bytes([lit]) + bytes(int(v) for v in row[x:x + lit])
+                    x += lit
+    path = tmp_path / "sky.hdr"
+    path.write_bytes(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (h, w) + bytes(body))
+    img = pkg.load_hdr(str(path))
+    assert img.shape == (h, w, 3)
+    want = quads[..., :3].astype(np.float32) / 256.0 * (2.0 ** (quads[..., 3:4].astype(np.float32) - 128))
+    assert np.array_equal(img, want.astype(np.float32))
+    tm = pkg.sky_tonemap(img)
+    ref = (1 + 1 / np.power(-1 - img.astype(np.float64), 5)).astype(np.float32)
+    assert np.allclose(tm, ref, rtol=1e-6) and tm.min() >= 0.0 and tm.max() < 1.0
+
+
+def test_scene_fixtures():
+    s = pkg.scene_readme()
+    assert s.S == 5 and s.spheres[0].radius == 100.0 and s.spheres[4].material.type == pkg.METAL
+    assert s.spheres[3].material.fuzz == 0.5 and s.spheres[0].material.albedo.tuple() == (0.0, np.float32(0.8), np.float32(0.7))
+    m = pkg.scene_main_cpp()
+    assert m.S == 8 and [m.spheres[i].material.type for i in range(8)] == [0, 0, 1, 1, 2, 3, 1, 1]
+    st = pkg.scene_stress(50, 8, 6, 2, 3)
+    assert st.S == 50 and st.T == 2 * 8 * 6 and st.B == 6
+    ids = np.array([st.triangles[i].boundingBoxId for i in range(st.T)])
+    assert np.all(np.diff(ids) >= 0) and set(ids) == set(range(6))
+    sky = pkg.sky_gradient(64, 32)
+    assert sky.shape == (32, 64, 3) and np.allclose(sky[0, 0], (0.5, 0.7, 1.0)) and np.allclose(sky[-1, 0], (1, 1, 1))
