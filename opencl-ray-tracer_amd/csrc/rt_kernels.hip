@@ -151,17 +151,161 @@ __device__ __forceinline__ F3 sky_lookup(const SceneDev &sc, F3 dir)
 	return ld3(sc.sky + 3 * (size_t)(y * sc.skyw + x));
 }
 
+
+// IEEE-correct num/den for three numerators that share one reciprocal refinement.
+// This is the hardware's own correctly-rounded division sequence (v_rcp_f32 + one Newton
+// step, then quotient + two residual corrections) without the operand scaling, which is
+// the identity while every operand sits well inside the normal range; outside it (or for
+// zero / non-finite operands) the compiler's full IEEE division is used instead.
+__device__ __forceinline__ F3 div3(F3 num, float den)
+{
+	const float lo = 0x1p-40f, hi = 0x1p40f;
+	const float ad = fabsf(den), ax = fabsf(num.x), ay = fabsf(num.y), az = fabsf(num.z);
+	const bool safe = ad >= lo && ad <= hi && ax >= lo && ax <= hi && ay >= lo && ay <= hi && az >= lo && az <= hi;
+	float y = __builtin_amdgcn_rcpf(den);
+	const float e = __builtin_fmaf(-den, y, 1.0f);
+	y = __builtin_fmaf(e, y, y);
+	F3 q;
+	{
+		float q0 = num.x * y; float r = __builtin_fmaf(-den, q0, num.x); q0 = __builtin_fmaf(r, y, q0);
+		r = __builtin_fmaf(-den, q0, num.x); q.x = __builtin_fmaf(r, y, q0);
+	}
+	{
+		float q0 = num.y * y; float r = __builtin_fmaf(-den, q0, num.y); q0 = __builtin_fmaf(r, y, q0);
+		r = __builtin_fmaf(-den, q0, num.y); q.y = __builtin_fmaf(r, y, q0);
+	}
+	{
+		float q0 = num.z * y; float r = __builtin_fmaf(-den, q0, num.z); q0 = __builtin_fmaf(r, y, q0);
+		r = __builtin_fmaf(-den, q0, num.z); q.z = __builtin_fmaf(r, y, q0);
+	}
+	if (!safe) q = num / den;
+	return q;
+}
+__device__ __forceinline__ F3 unit_fast(F3 a) { return div3(a, sqrtf(dot(a, a))); }
+
+// atan(a) for a in [0,1]: odd polynomial a*P(a^2), absolute error < 1.1e-7.
+__device__ __forceinline__ float atan01(float a)
+{
+	const float s = a * a;
+	float p = 2.834064187e-03f;
+	p = __builtin_fmaf(p, s, -1.600502990e-02f);
+	p = __builtin_fmaf(p, s, 4.258760810e-02f);
+	p = __builtin_fmaf(p, s, -7.495445758e-02f);
+	p = __builtin_fmaf(p, s, 1.063675433e-01f);
+	p = __builtin_fmaf(p, s, -1.420257092e-01f);
+	p = __builtin_fmaf(p, s, 1.999248415e-01f);
+	p = __builtin_fmaf(p, s, -3.333306611e-01f);
+	p = __builtin_fmaf(p, s, 1.0f);
+	return a * p;
+}
+
+// Sky texel index without the exact (double precision) path.  The texel is an integer, so
+// an approximation of the texel coordinates decides it whenever they are farther from a
+// texel boundary than the approximation's error bound; otherwise (rare) it reports failure
+// and the caller evaluates the defining sequence in sky_lookup().  Bounds: |u_fast - u| <=
+// 3.4e-7 and |v_fast - v| <= 4.2e-7 + 6.4e-8/cos(elevation) against the defining float
+// pipeline (its own roundings included); the bands below use 1e-6 and 1e-6 + 2e-7/cos.
+__device__ __forceinline__ bool sky_texel_fast(const SceneDev &sc, F3 d, int &idx)
+{
+	const float PI = 3.14159274101257324f, PI_2 = 1.57079637050628662f;
+	const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+	const float h2 = d.x * d.x + d.z * d.z;
+	const float l2 = h2 + d.y * d.y;
+	// azimuth atan2(z, x)
+	float hi = fmaxf(ax, az), lo = fminf(ax, az);
+	float r = atan01(lo * __builtin_amdgcn_rcpf(hi));
+	if (az > ax) r = PI_2 - r;
+	if (d.x < 0.0f) r = PI - r;
+	if (d.z < 0.0f) r = -r;
+	const float fx = __builtin_fmaf(r, 0.159154943091895346f, 0.5f) * (float)sc.skyw;
+	// elevation atan2(y, sqrt(x^2+z^2)) == asin(y/|d|)
+	const float hd = __builtin_amdgcn_sqrtf(h2);
+	hi = fmaxf(ay, hd); lo = fminf(ay, hd);
+	float e = atan01(lo * __builtin_amdgcn_rcpf(hi));
+	if (ay > hd) e = PI_2 - e;
+	if (d.y < 0.0f) e = -e;
+	const float fy = __builtin_fmaf(-e, 0.318309886183790691f, 0.5f) * (float)sc.skyh;
+	const float inv_cos = __builtin_amdgcn_sqrtf(l2) * __builtin_amdgcn_rcpf(hd);
+	const float bx = 1e-6f * (float)sc.skyw;
+	const float by = __builtin_fmaf(2e-7f, inv_cos, 1e-6f) * (float)sc.skyh;
+	const float x0 = floorf(fx - bx), x1 = floorf(fx + bx);
+	const float y0 = floorf(fy - by), y1 = floorf(fy + by);
+	const bool ok = x0 == x1 && y0 == y1 && x0 >= 0.0f && y0 >= 0.0f && x1 <= (float)(sc.skyw - 1) &&
+	                y1 <= (float)(sc.skyh - 1) && d.x != 0.0f && d.z != 0.0f && l2 > 1e-20f && l2 < 1e20f;
+	idx = (int)y0 * sc.skyw + (int)x0;
+	return ok;
+}
+
+// Closest sphere without per-sphere exact square roots and divisions.  All roots of one
+// segment share the divisor a = |d|^2 > 0 and correctly rounded division is monotonic, so
+// roots are ordered like their numerators n = -hb -+ sqrt(disc) unless two numerators are
+// within rounding distance.  The loop works on approximate numerators (hardware sqrt, 1 ulp)
+// with explicit error margins: every decision the reference takes (first root below tMin?
+// second root below tMin? closer than the best so far, later sphere winning ties) is taken
+// only when the margins make it certain; otherwise the lane reports failure and the caller
+// runs the exact loop.  The winner's root is then evaluated exactly, once.
+__device__ __forceinline__ bool spheres_fast(const SceneDev &sc, F3 o, F3 d, float a, float &t_out, int &id_out)
+{
+	const float tmin = 0.001f;
+	bool ok = a > 0.0f && a < 1e30f;
+	const float T = tmin * a;
+	const float T_lo = T * (1.0f - 4e-7f), T_hi = T * (1.0f + 4e-7f);
+	float best_n = INFINITY, best_m = 0.0f, best_hb = 0.0f, best_disc = 0.0f;
+	bool best_second = false;
+	int id = -1;
+	for (int i = 0; i < sc.S; ++i)
+	{
+		const float4 g = sc.sph_geom[i];
+		F3 oc = o - f3(g.x, g.y, g.z);
+		float hb = dot(oc, d);
+		float cc = dot(oc, oc) - g.w;
+		float disc = hb * hb - a * cc;
+		if (disc < 0.0f) continue;
+		ok = ok && (disc == 0.0f || (disc > 1e-30f && disc < 1e30f));
+		const float sq = __builtin_amdgcn_sqrtf(disc);
+		const float n1 = -hb - sq, n2 = -hb + sq;
+		// margin = |approximate - exact numerator| (1.5 ulp of the square root, plus the
+		// roundings of the two sums) + the distance below which two quotients may round
+		// to the same float
+		const float ms = 2e-7f * sq;
+		bool second = false;
+		float n = n1;
+		float m = __builtin_fmaf(3e-7f, fabsf(n1), ms);
+		if (n1 - m > T_hi) { }                      // first root certainly >= tMin
+		else if (n1 + m < T_lo)                      // first root certainly < tMin
+		{
+			second = true;
+			n = n2;
+			m = __builtin_fmaf(3e-7f, fabsf(n2), ms);
+			if (n2 - m > T_hi) { }
+			else if (n2 + m < T_lo) continue;        // both roots below tMin
+			else { ok = false; continue; }
+		}
+		else { ok = false; continue; }
+		if (n + m < best_n - best_m) { }             // certainly closer (or best is still +inf)
+		else if (n - m > best_n + best_m) continue;  // certainly farther
+		else { ok = false; continue; }
+		best_n = n; best_m = m; best_hb = hb; best_disc = disc; best_second = second; id = i;
+	}
+	id_out = id;
+	t_out = INFINITY;
+	if (id >= 0)
+	{
+		const float sq = sqrtf(best_disc);
+		t_out = (best_second ? (-best_hb + sq) : (-best_hb - sq)) / a;
+	}
+	return ok;
+}
+
 // ------------------------------------------------------------ intersection
 // gpu_kernel.cl:358-394 + :455-478 + :489-520 + :534-555.  Returns the primitive id
 // (sphere index, S + grouped triangle index, -1) and the accepted t.
 template <bool STATS>
-__device__ __forceinline__ int closest_hit(const SceneDev &sc, F3 o, F3 d, float &t_out, Counters<STATS> &ctr)
+__device__ __forceinline__ void spheres_exact(const SceneDev &sc, F3 o, F3 d, float a, float &closest, int &id, Counters<STATS> &ctr)
 {
 	const float tmin = 0.001f;
-	float closest = INFINITY;
-	int id = -1;
-	const float a = dot(d, d);
-	if (STATS) ctr.add(C_SPHERE_TESTS, (unsigned)sc.S);
+	closest = INFINITY;
+	id = -1;
 	for (int i = 0; i < sc.S; ++i)
 	{
 		const float4 g = sc.sph_geom[i];
@@ -183,52 +327,73 @@ __device__ __forceinline__ int closest_hit(const SceneDev &sc, F3 o, F3 d, float
 		closest = root;
 		id = i;
 	}
-	if (sc.B > 0)
+}
+
+template <bool STATS>
+__device__ __forceinline__ void boxes_and_triangles(const SceneDev &sc, F3 o, F3 d, float &closest, int &id, Counters<STATS> &ctr)
+{
+	const float tmin = 0.001f;
+	if (STATS) ctr.add(C_BBOX_TESTS, (unsigned)sc.B);
+	const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+	for (int b = 0; b < sc.B; ++b)
 	{
-		if (STATS) ctr.add(C_BBOX_TESTS, (unsigned)sc.B);
-		const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
-		for (int b = 0; b < sc.B; ++b)
+		const float4 mn = sc.box_min[b], mx = sc.box_max[b];
+		float tx1 = (mn.x - o.x) * ix, tx2 = (mx.x - o.x) * ix;
+		float lo = fminf(tx1, tx2), hi = fmaxf(tx1, tx2);
+		float ty1 = (mn.y - o.y) * iy, ty2 = (mx.y - o.y) * iy;
+		lo = fmaxf(lo, fminf(ty1, ty2));
+		hi = fminf(hi, fmaxf(ty1, ty2));
+		float tz1 = (mn.z - o.z) * iz, tz2 = (mx.z - o.z) * iz;
+		lo = fmaxf(lo, fminf(tz1, tz2));
+		hi = fminf(hi, fmaxf(tz1, tz2));
+		if (!(hi > fmaxf(lo, 0.0f))) continue;
+		if (STATS) ctr.add(C_BBOX_HITS, 1);
+		const int2 range = sc.box_range[b];
+		for (int j = range.x; j < range.y; ++j)
 		{
-			const float4 mn = sc.box_min[b], mx = sc.box_max[b];
-			float tx1 = (mn.x - o.x) * ix, tx2 = (mx.x - o.x) * ix;
-			float lo = fminf(tx1, tx2), hi = fmaxf(tx1, tx2);
-			float ty1 = (mn.y - o.y) * iy, ty2 = (mx.y - o.y) * iy;
-			lo = fmaxf(lo, fminf(ty1, ty2));
-			hi = fminf(hi, fmaxf(ty1, ty2));
-			float tz1 = (mn.z - o.z) * iz, tz2 = (mx.z - o.z) * iz;
-			lo = fmaxf(lo, fminf(tz1, tz2));
-			hi = fminf(hi, fmaxf(tz1, tz2));
-			if (!(hi > fmaxf(lo, 0.0f))) continue;
-			if (STATS) ctr.add(C_BBOX_HITS, 1);
-			const int2 range = sc.box_range[b];
-			for (int j = range.x; j < range.y; ++j)
+			const float4 g0 = sc.tri_geom[3 * j + 0];
+			const float4 g1 = sc.tri_geom[3 * j + 1];
+			const float4 g2 = sc.tri_geom[3 * j + 2];
+			const F3 p0 = f3(g0.x, g0.y, g0.z), e0 = f3(g0.w, g1.x, g1.y), e1 = f3(g1.z, g1.w, g2.x);
+			if (STATS) ctr.add(C_TRI_TESTS, 1);
+			F3 h = cross(d, e1);
+			float det = dot(e0, h);
+			if (det > -0.00001f && det < 0.00001f) { if (STATS) ctr.add(C_TRI_EXIT_PARALLEL, 1); continue; }
+			float f = 1.0f / det;
+			F3 s = o - p0;
+			float u = f * dot(s, h);
+			if (u < 0.0f || u > 1.0f) { if (STATS) ctr.add(C_TRI_EXIT_U, 1); continue; }
+			F3 q = cross(s, e0);
+			float v = f * dot(d, q);
+			if (v < 0.0f || u + v > 1.0f) { if (STATS) ctr.add(C_TRI_EXIT_V, 1); continue; }
+			if (STATS) ctr.add(C_TRI_REACH_T, 1);
+			float t0 = f * dot(e1, q);
+			if (t0 > tmin && t0 < closest)
 			{
-				const float4 g0 = sc.tri_geom[3 * j + 0];
-				const float4 g1 = sc.tri_geom[3 * j + 1];
-				const float4 g2 = sc.tri_geom[3 * j + 2];
-				const F3 p0 = f3(g0.x, g0.y, g0.z), e0 = f3(g0.w, g1.x, g1.y), e1 = f3(g1.z, g1.w, g2.x);
-				if (STATS) ctr.add(C_TRI_TESTS, 1);
-				F3 h = cross(d, e1);
-				float det = dot(e0, h);
-				if (det > -0.00001f && det < 0.00001f) { if (STATS) ctr.add(C_TRI_EXIT_PARALLEL, 1); continue; }
-				float f = 1.0f / det;
-				F3 s = o - p0;
-				float u = f * dot(s, h);
-				if (u < 0.0f || u > 1.0f) { if (STATS) ctr.add(C_TRI_EXIT_U, 1); continue; }
-				F3 q = cross(s, e0);
-				float v = f * dot(d, q);
-				if (v < 0.0f || u + v > 1.0f) { if (STATS) ctr.add(C_TRI_EXIT_V, 1); continue; }
-				if (STATS) ctr.add(C_TRI_REACH_T, 1);
-				float t0 = f * dot(e1, q);
-				if (t0 > tmin && t0 < closest)
-				{
-					if (STATS) ctr.add(C_TRI_ACCEPT, 1);
-					closest = t0;
-					id = sc.S + j;
-				}
+				if (STATS) ctr.add(C_TRI_ACCEPT, 1);
+				closest = t0;
+				id = sc.S + j;
 			}
 		}
 	}
+}
+
+// The counting build always takes the exact sphere loop: its counters are defined by the
+// reference's sequential order of decisions.
+template <bool STATS>
+__device__ __forceinline__ int closest_hit(const SceneDev &sc, F3 o, F3 d, float &t_out, Counters<STATS> &ctr)
+{
+	float closest = INFINITY;
+	int id = -1;
+	const float a = dot(d, d);
+	if (STATS)
+	{
+		ctr.add(C_SPHERE_TESTS, (unsigned)sc.S);
+		spheres_exact<STATS>(sc, o, d, a, closest, id, ctr);
+	}
+	else if (!spheres_fast(sc, o, d, a, closest, id))
+		spheres_exact<STATS>(sc, o, d, a, closest, id, ctr);
+	if (sc.B > 0) boxes_and_triangles<STATS>(sc, o, d, closest, id, ctr);
 	t_out = closest;
 	return id;
 }
@@ -367,7 +532,7 @@ __global__ __launch_bounds__(256) void k_render(const RenderParams p)
 				if (id < sc.S)
 				{
 					const float4 g = sc.sph_geom[id];
-					outward = (hp - f3(g.x, g.y, g.z)) / sc.sph_radius[id];
+					outward = div3(hp - f3(g.x, g.y, g.z), sc.sph_radius[id]);
 					ma = sc.sph_mat_a[id];
 					mb = sc.sph_mat_b[id];
 				}
@@ -377,7 +542,7 @@ __global__ __launch_bounds__(256) void k_render(const RenderParams p)
 					const float4 g0 = sc.tri_geom[3 * j + 0];
 					const float4 g1 = sc.tri_geom[3 * j + 1];
 					const float4 g2 = sc.tri_geom[3 * j + 2];
-					outward = unit(cross(f3(g0.w, g1.x, g1.y), f3(g1.z, g1.w, g2.x)));
+					outward = unit_fast(cross(f3(g0.w, g1.x, g1.y), f3(g1.z, g1.w, g2.x)));
 					ma = sc.tri_mat_a[j];
 					mb = sc.tri_mat_b[j];
 				}
@@ -386,13 +551,24 @@ __global__ __launch_bounds__(256) void k_render(const RenderParams p)
 				const F3 albedo = f3(ma.x, ma.y, ma.z);
 				const float fuzz = ma.w, ior = mb.x;
 				const int type = __float_as_int(mb.y);
+
+				// Steps shared by the material types, so lanes with different materials run
+				// them together: (1) a point in the unit sphere for Lambertian and fuzzy-metal
+				// lanes (same draws, same order as gpu_kernel.cl:400 / :419 — reflecting first
+				// consumes no draws); (2) one normalisation: of that point (Lambertian) or of
+				// the incoming direction (metal, dielectric).
+				F3 rv = f3(0.0f, 0.0f, 0.0f);
+				if (type == 0 || (type == 1 && fuzz > 0.0f)) rv = rand_in_unit_sphere<STATS>(L.rng, ctr);
+				F3 un = f3(0.0f, 0.0f, 0.0f);
+				if (type == 0 || type == 1 || type == 2) un = unit_fast(type == 0 ? rv : L.d);
+
 				bool scattered = true;
 				F3 nd = L.d;
 				F3 att = f3(1.0f, 1.0f, 1.0f);
 				if (type == 0) // gpu_kernel.cl:398-413
 				{
 					if (STATS) ctr.add(C_LAMBERT, 1);
-					nd = n + unit(rand_in_unit_sphere<STATS>(L.rng, ctr));
+					nd = n + un;
 					const float eps = 1e-8f;
 					if (fabsf(nd.x) < eps && fabsf(nd.y) < eps && fabsf(nd.z) < eps) nd = n;
 					att = albedo;
@@ -400,11 +576,11 @@ __global__ __launch_bounds__(256) void k_render(const RenderParams p)
 				else if (type == 1) // gpu_kernel.cl:415-423
 				{
 					if (STATS) ctr.add(C_METAL, 1);
-					nd = reflect(unit(L.d), n);
+					nd = reflect(un, n);
 					if (fuzz > 0.0f)
 					{
 						if (STATS) ctr.add(C_METAL_FUZZ, 1);
-						nd = nd + rand_in_unit_sphere<STATS>(L.rng, ctr) * fuzz;
+						nd = nd + rv * fuzz;
 					}
 					att = albedo;
 					if (!(dot(nd, n) > 0))
@@ -418,7 +594,7 @@ __global__ __launch_bounds__(256) void k_render(const RenderParams p)
 				{
 					if (STATS) ctr.add(C_DIELECTRIC, 1);
 					const float ratio = front ? (1.0f / ior) : ior;
-					const F3 ud = unit(L.d);
+					const F3 ud = un;
 					const float cos_t = fminf(dot(ud * -1.0f, n), 1.0f);
 					const float sin_t = sqrtf(1.0f - cos_t * cos_t);
 					bool refl = ratio * sin_t > 1.0f;
@@ -465,7 +641,11 @@ __global__ __launch_bounds__(256) void k_render(const RenderParams p)
 		if (outcome == 2)
 		{
 			if (STATS) ctr.add(C_MISS, 1);
-			col = L.thr * sky_lookup(sc, L.d);
+			int texel = 0;
+			const bool decided = !STATS && sky_texel_fast(sc, L.d, texel);
+			F3 sky = ld3(sc.sky + 3 * (size_t)(decided ? texel : 0));
+			if (!decided) sky = sky_lookup(sc, L.d); // exact texel coordinates (rare)
+			col = L.thr * sky;
 		}
 		if (outcome != 0)
 		{
@@ -532,7 +712,8 @@ __global__ void k_tonemap(const float *image, float scale, int width, int height
 	}
 }
 
-// op: 0 a/b, 1 sqrtf(a), 2 atan2(a,b), 3 asin(a), 4 a^5, 5 rng float of seed bits a (32-bit) after b draws
+// op: 0 a/b, 1 sqrtf(a), 2 atan2(a,b), 3 asin(a), 4 a^5, 5 rng float of seed bits a (32-bit) after b draws,
+// 6 shared-reciprocal division a/b, 7/8 sky texel index (fast with fallback / exact)
 __global__ void k_math_probe(int op, const float *a, const float *b, float *out, int n)
 {
 	int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -550,6 +731,28 @@ __global__ void k_math_probe(int op, const float *a, const float *b, float *out,
 		Rng g; g.s = (unsigned long long)__float_as_uint(x);
 		int k = (int)__float_as_uint(y);
 		for (int j = 0; j < k; ++j) r = g.next();
+		break;
+	}
+	case 6: r = div3(f3(x, x, x), y).z; break;
+	case 7: // sky texel of direction (a, b, 0.25 - a) in a 64x32 map: fast path with exact fallback
+	case 8: // same, exact path only
+	{
+		SceneDev sc{};
+		sc.skyw = 64; sc.skyh = 32;
+		F3 d = f3(x, y, 0.25f - x);
+		int idx = 0;
+		if (op == 8 || !sky_texel_fast(sc, d, idx))
+		{
+			F3 n = unit(d);
+			float u = 0.5f + pt_atan2f(n.z, n.x) / (2.0f * 3.14159274101257324f);
+			float v = 0.5f - pt_asinf(n.y) / 3.14159274101257324f;
+			float fx = u * 64.0f, fy = v * 32.0f;
+			int xi = (fx >= 0.0f && fx <= 64.0f) ? (int)fx : 0;
+			int yi = (fy >= 0.0f && fy <= 32.0f) ? (int)fy : 0;
+			idx = yi * 64 + xi;
+			if (op == 7) idx += 1 << 20; // marks a fallback
+		}
+		r = (float)idx;
 		break;
 	}
 	}

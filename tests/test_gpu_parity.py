@@ -39,6 +39,41 @@ def test_device_float_primitives_are_ieee(gpu_ctx):
     assert np.array_equal(bits(gpu_ctx.math_probe(4, u)), bits(want))
 
 
+def test_fast_paths_equal_exact_paths(gpu_ctx):
+    """The shared-reciprocal division and the fast sky-texel path must be indistinguishable
+    from the IEEE division and from the exact (double precision) texel coordinates."""
+    rs = np.random.RandomState(2)
+    n = 1 << 18
+    a = (rs.standard_normal(n) * 10 ** rs.uniform(-15, 15, n)).astype(np.float32)
+    b = (rs.standard_normal(n) * 10 ** rs.uniform(-15, 15, n)).astype(np.float32)
+    a[:8] = [0.0, -0.0, 1.0, 1e-39, 3e38, 1.0, np.inf, np.nan]
+    b[:8] = [2.0, 2.0, 0.0, 3.0, 1e-3, 3e-39, 2.0, 1.0]
+    with np.errstate(all="ignore"):
+        assert np.array_equal(bits(gpu_ctx.math_probe(6, a, b)), bits(a / b))
+    c = rs.uniform(-1, 1, n).astype(np.float32)
+    d = rs.uniform(-1, 1, n).astype(np.float32)
+    # rays clustered near texel boundaries, the poles and the axes as well
+    c[: n // 8] = (rs.uniform(-1, 1, n // 8) * 1e-4).astype(np.float32)
+    d[n // 8: n // 4] = (1.0 - np.abs(rs.standard_normal(n // 8)) * 1e-5).astype(np.float32)
+    c[n // 4: n // 4 + 16] = 0.0
+    fast = gpu_ctx.math_probe(7, c, d).astype(np.int64)
+    exact = gpu_ctx.math_probe(8, c, d).astype(np.int64)
+    fell_back = fast >= (1 << 20)
+    assert np.array_equal(np.where(fell_back, fast - (1 << 20), fast), exact)
+    assert fell_back.mean() < 0.05  # the fast path decides the overwhelming majority
+    # and the exact path is the oracle's definition
+    import ctypes as C
+    ol.wbo_to_uv.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    for i in range(0, 4096):
+        v = pkg.vec3(c[i], d[i], np.float32(0.25) - c[i])
+        out = (C.c_float * 2)()
+        ol.wbo_to_uv(C.byref(v), orc.MATH_PORTABLE, out)
+        fx, fy = np.float32(out[0]) * np.float32(64), np.float32(out[1]) * np.float32(32)
+        xi = int(fx) if 0 <= fx <= 64 else 0
+        yi = int(fy) if 0 <= fy <= 32 else 0
+        assert exact[i] == yi * 64 + xi
+
+
 def test_device_rng_matches_golden(gpu_ctx):
     z = golden("rng_kat.npz")
     seeds = z["seeds"].astype(np.uint32)  # the kernel seeds are 32-bit (gpu_kernel.cl:598,606)
