@@ -15,7 +15,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libocl_rt_amd.so")
+LIB_PATH = os.environ.get("WBRT_LIB") or os.path.join(_HERE, "libocl_rt_amd.so")  # override: kernel A/B experiments
 CSRC = os.path.join(_HERE, "csrc")
 
 OUT_MEAN, OUT_SUM, OUT_ACCUMULATE = 0, 1, 2

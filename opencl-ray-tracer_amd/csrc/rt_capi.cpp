@@ -5,6 +5,7 @@
 #include "rt_device.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <utility>
@@ -64,7 +65,9 @@ struct wbrt_context
 	DevBuf sph_geom, sph_radius, sph_mat_a, sph_mat_b;
 	DevBuf tri_geom, tri_mat_a, tri_mat_b, tri_orig;
 	DevBuf box_min, box_max, box_range;
-	DevBuf sky, seeds, image, ids, counters, rgb8;
+	DevBuf sky, seeds, image, ids, counters, rgb8, costs, tile_costs, order, hist;
+	int lpt = 1;        // longest-first scheduling from a pilot pass
+	int pilot_spp = 4;
 	SceneDev sc{};
 	bool have_scene = false, have_sky = false;
 	size_t n_seeds = 0;
@@ -93,7 +96,8 @@ int make_params(wbrt_context *ctx, const wbrt_camera *cam, bool whole_frame, Ren
 	if (cam->samplesPerPixel < 0) return fail(WBRT_ERR_INVALID, "samplesPerPixel must be >= 0");
 	if ((size_t)bsx * (size_t)bsy > ctx->n_seeds)
 		return fail(WBRT_ERR_INVALID, "seed buffer smaller than one block (wbrt_upload_seeds)");
-	if ((long long)cam->width * cam->height > (1LL << 30)) return fail(WBRT_ERR_INVALID, "image too large");
+	if ((long long)cam->width * cam->height > (1LL << 30) || cam->width > (1 << 23) || cam->height > (1 << 23))
+		return fail(WBRT_ERR_INVALID, "image too large");
 	std::memset(&p, 0, sizeof p);
 	const wbrt_vec3 *src[6] = { &cam->origin, &cam->horizontal, &cam->vertical, &cam->lowerLeftCorner,
 	                            &cam->defocusDiscU, &cam->defocusDiscV };
@@ -101,6 +105,7 @@ int make_params(wbrt_context *ctx, const wbrt_camera *cam, bool whole_frame, Ren
 	for (int i = 0; i < 6; ++i) { dst[i][0] = src[i]->x; dst[i][1] = src[i]->y; dst[i][2] = src[i]->z; }
 	p.aperture = cam->aperture;
 	p.width = cam->width; p.height = cam->height;
+	p.inv_width = (float)(1.0 / (double)cam->width); p.inv_height = (float)(1.0 / (double)cam->height);
 	p.spp = cam->samplesPerPixel; p.max_depth = cam->maxDepth;
 	p.bsx = bsx; p.bsy = bsy;
 	if (whole_frame)
@@ -131,7 +136,27 @@ int timed_launch(wbrt_context *ctx, const RenderParams &p, hipStream_t stream)
 		HIP_TRY(hipEventCreate(&b));
 		HIP_TRY(hipEventRecord(a, stream));
 	}
-	HIP_TRY(wbrt_launch_render(p, stream));
+	// Longest-first schedule (see k_render): a pilot launch with a few samples per pixel prices
+	// every pixel stream, a counting sort orders them, the real launch follows that order.
+	RenderParams q = p;
+	const long long total = (long long)p.bsx * p.bsy * p.nbx * p.nby;
+	if (ctx->lpt && total >= 65536 && total % 64 == 0 && p.spp >= 8 * ctx->pilot_spp)
+	{
+		int rc = ctx->costs.reserve((size_t)total * sizeof(int));
+		if (!rc) rc = ctx->order.reserve((size_t)(total / 64 + 1) * sizeof(int));
+		if (!rc) rc = ctx->tile_costs.reserve((size_t)(total / 64 + 1) * sizeof(int));
+		if (!rc) rc = ctx->hist.reserve(256 * sizeof(unsigned));
+		if (rc) return rc;
+		RenderParams pilot = p;
+		pilot.spp = ctx->pilot_spp;
+		pilot.costs = (int *)ctx->costs.p;
+		pilot.out = nullptr;
+		HIP_TRY(wbrt_launch_render(pilot, stream));
+		HIP_TRY(wbrt_launch_cost_sort((const int *)ctx->costs.p, (int)total, ctx->pilot_spp, (int *)ctx->tile_costs.p,
+		                              (unsigned *)ctx->hist.p, (int *)ctx->order.p, stream));
+		q.order = (const int *)ctx->order.p;
+	}
+	HIP_TRY(wbrt_launch_render(q, stream));
 	if (ctx->timing)
 	{
 		HIP_TRY(hipEventRecord(b, stream));
@@ -161,6 +186,9 @@ int wbrt_create(int device_ordinal, wbrt_context **out)
 	ctx->device = device_ordinal;
 	e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
 	if (e != hipSuccess) { delete ctx; return fail(WBRT_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorName(e)); }
+	// tuning knobs for experiments (not part of the ABI contract)
+	if (const char *v = std::getenv("WBRT_LPT")) ctx->lpt = std::atoi(v) != 0;
+	if (const char *v = std::getenv("WBRT_PILOT_SPP")) ctx->pilot_spp = std::atoi(v) > 0 ? std::atoi(v) : 4;
 	*out = ctx;
 	return WBRT_OK;
 }
@@ -173,7 +201,8 @@ int wbrt_destroy(wbrt_context *ctx)
 	for (auto &ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
 	DevBuf *all[] = { &ctx->sph_geom, &ctx->sph_radius, &ctx->sph_mat_a, &ctx->sph_mat_b, &ctx->tri_geom,
 	                  &ctx->tri_mat_a, &ctx->tri_mat_b, &ctx->tri_orig, &ctx->box_min, &ctx->box_max,
-	                  &ctx->box_range, &ctx->sky, &ctx->seeds, &ctx->image, &ctx->ids, &ctx->counters, &ctx->rgb8 };
+	                  &ctx->box_range, &ctx->sky, &ctx->seeds, &ctx->image, &ctx->ids, &ctx->counters, &ctx->rgb8,
+	                  &ctx->costs, &ctx->tile_costs, &ctx->order, &ctx->hist };
 	for (DevBuf *b : all) b->release();
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
@@ -437,6 +466,29 @@ int wbrt_device_info(wbrt_context *ctx, char *buf, size_t buf_len)
 	              "device %d: %s (%s), %d CUs, %d MHz, %.1f GiB, LDS/block %zu B, wave %d",
 	              ctx->device, prop.name, prop.gcnArchName, prop.multiProcessorCount, prop.clockRate / 1000,
 	              (double)prop.totalGlobalMem / (1024.0 * 1024.0 * 1024.0), prop.sharedMemPerBlock, prop.warpSize);
+	return WBRT_OK;
+}
+
+// Test hook (not in the public header): loop iterations (ray segments) each pixel took.
+int wbrt_pixel_costs_(wbrt_context *ctx, const wbrt_camera *camera, int32_t *host_costs)
+{
+	int rc = bind(ctx);
+	if (rc) return rc;
+	RenderParams p;
+	rc = make_params(ctx, camera, true, p);
+	if (rc) return rc;
+	size_t bytes = WBRT_NUM_COUNTERS * sizeof(unsigned long long);
+	rc = ctx->counters.reserve(bytes);
+	if (rc) return rc;
+	size_t cbytes = (size_t)p.width * p.height * sizeof(int32_t);
+	rc = ctx->ids.reserve(cbytes);
+	if (rc) return rc;
+	HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, bytes, ctx->stream));
+	p.counters = (unsigned long long *)ctx->counters.p;
+	p.costs = (int *)ctx->ids.p;
+	HIP_TRY(wbrt_launch_render(p, ctx->stream));
+	HIP_TRY(hipMemcpyAsync(host_costs, p.costs, cbytes, hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
 	return WBRT_OK;
 }
 

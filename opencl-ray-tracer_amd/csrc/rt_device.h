@@ -51,6 +51,7 @@ struct RenderParams
 	float org[3], hor[3], ver[3], llc[3], ddu[3], ddv[3];
 	float aperture;
 	int width, height, spp, max_depth;
+	float inv_width, inv_height;    // correctly rounded 1/width, 1/height
 	// tiling: blocks of bsx*bsy pixels; this launch covers nbx*nby blocks whose block
 	// indices start at (off_bx, off_by)
 	int bsx, bsy, nbx, nby, off_bx, off_by;
@@ -60,6 +61,8 @@ struct RenderParams
 	float *out;
 	int *ids;                       // primary-id launch only
 	unsigned long long *counters;   // counting launch only
+	int *costs;                     // pilot launch: loop iterations per work index (no image is written)
+	const int *order;               // optional: waves (groups of 64 work indices) sorted by estimated cost, descending
 	const uint32_t *seeds;
 	SceneDev sc;
 };
@@ -67,6 +70,7 @@ struct RenderParams
 hipError_t wbrt_launch_render(const RenderParams &p, hipStream_t stream);
 hipError_t wbrt_launch_count(const RenderParams &p, hipStream_t stream);
 hipError_t wbrt_launch_ids(const RenderParams &p, hipStream_t stream);
+hipError_t wbrt_launch_cost_sort(const int *costs, int n, int pilot_spp, int *tile_costs, unsigned *hist, int *order, hipStream_t stream);
 hipError_t wbrt_launch_tonemap(const float *image, float scale, int width, int height, uint8_t *rgb8, hipStream_t stream);
 // evaluates the device's float / double primitives on arrays (known-answer tests)
 hipError_t wbrt_launch_math_probe(int op, const float *a, const float *b, float *out, int n, hipStream_t stream);

@@ -67,16 +67,29 @@ template <> struct Counters<true>
 };
 
 // --------------------------------------------------------------------- RNG
-// gpu_kernel.cl:582-591: 48-bit LCG; float = (s >> 16) converted with round-to-nearest,
-// divided by 2^32 (an exact scaling).
+// gpu_kernel.cl:582-591: 48-bit LCG s' = (s*0x5DEECE66D + 0xB) mod 2^48; the float is
+// bits 47..16 of the new state converted with round-to-nearest and divided by 2^32.
+// The state is held as lo (bits 0..31) and hi (bits 32..47).  With M = 0xDEECE66D + 5*2^32:
+//   s*M + 0xB == lo*0xDEECE66D + 0xB + ((lo*5 + hi*0xDEECE66D) << 32)      (mod 2^48)
+// Scaling by a power of two is exact, so callers fold the 2^-32 into a fused multiply-add
+// (see unit()/bipolar()): fma(top, 2^-31, -1) is bit-identical to (top*2^-32)*2 - 1.
 struct Rng
 {
-	unsigned long long s;
-	__device__ __forceinline__ float next()
+	unsigned lo, hi;
+	__device__ __forceinline__ void seed(unsigned s32) { lo = s32; hi = 0; }
+	// advances the state, returns float(state >> 16) (an integer value in [0, 2^32])
+	__device__ __forceinline__ float next_top()
 	{
-		s = (s * 0x5DEECE66DULL + 0xBULL) & 0xFFFFFFFFFFFFULL;
-		return (float)(unsigned)(s >> 16) * 2.3283064365386963e-10f;
+		const unsigned long long p = (unsigned long long)lo * 0xDEECE66Du + 0xBu;
+		const unsigned upper = (unsigned)(p >> 32) + (lo << 2) + lo + hi * 0xE66Du; // only 16 bits matter
+		lo = (unsigned)p;
+		hi = upper & 0xFFFFu;
+		return (float)((hi << 16) | (lo >> 16));
 	}
+	// the reference's draw in [0,1]
+	__device__ __forceinline__ float next() { return next_top() * 2.3283064365386963e-10f; }
+	// draw*2 - 1  (gpu_kernel.cl:187-189, :248-249)
+	__device__ __forceinline__ float bipolar() { return __builtin_fmaf(next_top(), 4.6566128730773926e-10f, -1.0f); }
 };
 
 // ---------------------------------------------- portable transcendental math
@@ -183,6 +196,20 @@ __device__ __forceinline__ F3 div3(F3 num, float den)
 }
 __device__ __forceinline__ F3 unit_fast(F3 a) { return div3(a, sqrtf(dot(a, a))); }
 
+// IEEE-correct x/den for 0 <= x < 2^24 and an integer-valued 1 <= den <= 2^24 whose
+// reciprocal rcp (within 1 ulp) is precomputed: same quotient + two residual corrections as
+// div3; every intermediate stays in the normal range for such operands.
+__device__ __forceinline__ float div_by_const(float x, float den, float rcp)
+{
+	float q = x * rcp;
+	float r = __builtin_fmaf(-den, q, x);
+	q = __builtin_fmaf(r, rcp, q);
+	r = __builtin_fmaf(-den, q, x);
+	q = __builtin_fmaf(r, rcp, q);
+	const bool safe = x < 16777216.0f && (x == 0.0f || x > 0x1p-60f);
+	return safe ? q : x / den;
+}
+
 // atan(a) for a in [0,1]: odd polynomial a*P(a^2), absolute error < 1.1e-7.
 __device__ __forceinline__ float atan01(float a)
 {
@@ -253,9 +280,12 @@ __device__ __forceinline__ bool spheres_fast(const SceneDev &sc, F3 o, F3 d, flo
 	float best_n = INFINITY, best_m = 0.0f, best_hb = 0.0f, best_disc = 0.0f;
 	bool best_second = false;
 	int id = -1;
+	float4 g_next = sc.S > 0 ? sc.sph_geom[0] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 	for (int i = 0; i < sc.S; ++i)
 	{
-		const float4 g = sc.sph_geom[i];
+		// the next sphere's scalar load is issued before this sphere's arithmetic
+		const float4 g = g_next;
+		g_next = sc.sph_geom[i + 1 < sc.S ? i + 1 : i];
 		F3 oc = o - f3(g.x, g.y, g.z);
 		float hb = dot(oc, d);
 		float cc = dot(oc, oc) - g.w;
@@ -405,9 +435,9 @@ __device__ __forceinline__ F3 rand_in_unit_sphere(Rng &rng, Counters<STATS> &ctr
 	for (;;)
 	{
 		if (STATS) { ctr.add(C_SPHERE_TRIES, 1); ctr.add(C_RNG_DRAWS, 3); }
-		float x = rng.next() * 2.0f - 1.0f;
-		float y = rng.next() * 2.0f - 1.0f;
-		float z = rng.next() * 2.0f - 1.0f;
+		float x = rng.bipolar();
+		float y = rng.bipolar();
+		float z = rng.bipolar();
 		F3 p = f3(x, y, z);
 		if (dot(p, p) >= 1.0f) continue;
 		return p;
@@ -433,8 +463,11 @@ template <bool STATS>
 __device__ __forceinline__ void camera_ray(const RenderParams &p, Lane &L, Counters<STATS> &ctr)
 {
 	if (STATS) { ctr.add(C_PATHS, 1); ctr.add(C_RNG_DRAWS, 2); }
-	float u = (L.base_u + L.rng.next()) / (float)p.width;
-	float v = (L.base_v + L.rng.next()) / (float)p.height;
+	// base + draw: the draw is top*2^-32 exactly, so the fused form rounds once, identically
+	const float su = __builtin_fmaf(L.rng.next_top(), 2.3283064365386963e-10f, L.base_u);
+	const float sv = __builtin_fmaf(L.rng.next_top(), 2.3283064365386963e-10f, L.base_v);
+	const float u = div_by_const(su, (float)p.width, p.inv_width);
+	const float v = div_by_const(sv, (float)p.height, p.inv_height);
 	F3 org = ld3(p.org);
 	if (!(p.aperture <= 0))
 	{
@@ -442,8 +475,8 @@ __device__ __forceinline__ void camera_ray(const RenderParams &p, Lane &L, Count
 		for (;;) // gpu_kernel.cl:243-257
 		{
 			if (STATS) { ctr.add(C_DISK_TRIES, 1); ctr.add(C_RNG_DRAWS, 2); }
-			dx = L.rng.next() * 2.0f - 1.0f;
-			dy = L.rng.next() * 2.0f - 1.0f;
+			dx = L.rng.bipolar();
+			dy = L.rng.bipolar();
 			if (dx * dx + dy * dy + 0.0f * 0.0f >= 1.0f) continue;
 			break;
 		}
@@ -481,7 +514,7 @@ __device__ __forceinline__ bool locate(const RenderParams &p, long long w, int &
 
 __device__ __forceinline__ void init_lane(const RenderParams &p, Lane &L, int gid, int bx, int by)
 {
-	L.rng.s = (unsigned long long)p.seeds[gid];
+	L.rng.seed(p.seeds[gid]);
 	L.base_u = (float)(gid % p.bsx) + ((float)p.bsx * (float)(bx + p.off_bx));
 	L.base_v = (float)(gid / p.bsx) + ((float)p.bsy * (float)(by + p.off_by));
 	L.sum = f3(0.0f, 0.0f, 0.0f);
@@ -495,10 +528,23 @@ __global__ __launch_bounds__(256) void k_render(const RenderParams p)
 	const SceneDev &sc = p.sc;
 	long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
 	int gid = 0, bx = 0, by = 0;
-	bool alive = locate(p, w, gid, bx, by);
+	long long work = w;
+	if (p.order)
+	{
+		// Longest-first schedule: waves (64 consecutive work indices, an 8x8 pixel tile when the
+		// block size allows) arrive sorted by estimated cost (descending), so the costliest
+		// pixel streams start first; their waves also get a higher issue priority,
+		// because the frame cannot finish before its longest stream does.
+		if (w < (long long)p.bsx * p.bsy * p.nbx * p.nby) work = (long long)p.order[w >> 6] * 64 + (w & 63);
+		const unsigned pos = blockIdx.x, n = gridDim.x;
+		if (pos * 50u < n) __builtin_amdgcn_s_setprio(3);
+		else if (pos * 10u < n) __builtin_amdgcn_s_setprio(2);
+		else if (pos * 3u < n) __builtin_amdgcn_s_setprio(1);
+	}
+	bool alive = locate(p, work, gid, bx, by);
 	Lane L;
 	L.o = L.d = L.thr = L.sum = f3(0, 0, 0);
-	L.rng.s = 0; L.base_u = L.base_v = 0; L.depth = 0; L.sample = 0;
+	L.rng.lo = L.rng.hi = 0; L.base_u = L.base_v = 0; L.depth = 0; L.sample = 0;
 	if (alive)
 	{
 		init_lane(p, L, gid, bx, by);
@@ -506,8 +552,10 @@ __global__ __launch_bounds__(256) void k_render(const RenderParams p)
 		if (alive) camera_ray<STATS>(p, L, ctr);
 	}
 
+	int iterations = 0;
 	while (alive) // lanes of a wave leave together only when all are done; others idle
 	{
+		++iterations;
 		// 0 = path continues, 1 = ended black, 2 = ended on the sky, 3 = ended with `col`
 		int outcome = 0;
 		F3 col = f3(0.0f, 0.0f, 0.0f);
@@ -671,6 +719,11 @@ __global__ __launch_bounds__(256) void k_render(const RenderParams p)
 		ctr.flush(p.counters);
 		return;
 	}
+	if (p.costs) // pilot launch: only the loop iterations (ray segments) of each work index
+	{
+		if (w < (long long)p.bsx * p.bsy * p.nbx * p.nby) p.costs[w] = iterations;
+		return;
+	}
 	if (w < (long long)p.bsx * p.bsy * p.nbx * p.nby)
 	{
 		const int row = gid / p.bsx + p.bsy * by, colx = gid % p.bsx + p.bsx * bx;
@@ -728,12 +781,13 @@ __global__ void k_math_probe(int op, const float *a, const float *b, float *out,
 	case 4: r = pt_pow5f(x); break;
 	case 5:
 	{
-		Rng g; g.s = (unsigned long long)__float_as_uint(x);
+		Rng g; g.seed(__float_as_uint(x));
 		int k = (int)__float_as_uint(y);
 		for (int j = 0; j < k; ++j) r = g.next();
 		break;
 	}
 	case 6: r = div3(f3(x, x, x), y).z; break;
+	case 9: r = div_by_const(x, y, 1.0f / y); break;
 	case 7: // sky texel of direction (a, b, 0.25 - a) in a 64x32 map: fast path with exact fallback
 	case 8: // same, exact path only
 	{
@@ -759,6 +813,40 @@ __global__ void k_math_probe(int op, const float *a, const float *b, float *out,
 	out[i] = r;
 }
 
+// Cost of a wave's 64 work indices = sum of their pilot iteration counts, scaled into 0..255.
+__global__ void k_tile_cost(const int *costs, int n, int n_tiles, int shift, int *tile_costs)
+{
+	const int tile = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+	const int i = tile * 64 + (threadIdx.x & 63);
+	int c = (tile < n_tiles && i < n) ? costs[i] : 0;
+	for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+	if ((threadIdx.x & 63) == 0 && tile < n_tiles) tile_costs[tile] = c >> shift;
+}
+
+// Counting sort of indices by cost, descending (256 buckets).
+__global__ void k_cost_hist(const int *costs, int n, unsigned *hist)
+{
+	__shared__ unsigned local[256];
+	local[threadIdx.x] = 0;
+	__syncthreads();
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+		atomicAdd(&local[min(costs[i], 255)], 1u);
+	__syncthreads();
+	if (local[threadIdx.x]) atomicAdd(&hist[threadIdx.x], local[threadIdx.x]);
+}
+
+__global__ void k_cost_scan(unsigned *hist) // one thread: bucket 255 first
+{
+	unsigned run = 0;
+	for (int b = 255; b >= 0; --b) { unsigned c = hist[b]; hist[b] = run; run += c; }
+}
+
+__global__ void k_cost_scatter(const int *costs, int n, unsigned *offsets, int *order)
+{
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+		order[atomicAdd(&offsets[min(costs[i], 255)], 1u)] = i;
+}
+
 inline unsigned grid_for(const RenderParams &p)
 {
 	long long total = (long long)p.bsx * p.bsy * p.nbx * p.nby;
@@ -776,6 +864,20 @@ hipError_t wbrt_launch_render(const RenderParams &p, hipStream_t stream)
 hipError_t wbrt_launch_count(const RenderParams &p, hipStream_t stream)
 {
 	hipLaunchKernelGGL(k_render<true>, dim3(grid_for(p)), dim3(256), 0, stream, p);
+	return hipGetLastError();
+}
+
+hipError_t wbrt_launch_cost_sort(const int *costs, int n, int pilot_spp, int *tile_costs, unsigned *hist, int *order, hipStream_t stream)
+{
+	const int n_tiles = (n + 63) / 64;
+	int shift = 0; // a tile whose 64 streams average 16 segments per sample lands in the last bucket
+	while (((64 * 16 * pilot_spp) >> shift) > 255) ++shift;
+	hipError_t e = hipMemsetAsync(hist, 0, 256 * sizeof(unsigned), stream);
+	if (e != hipSuccess) return e;
+	hipLaunchKernelGGL(k_tile_cost, dim3((n_tiles + 3) / 4), dim3(256), 0, stream, costs, n, n_tiles, shift, tile_costs);
+	hipLaunchKernelGGL(k_cost_hist, dim3(64), dim3(256), 0, stream, (const int *)tile_costs, n_tiles, hist);
+	hipLaunchKernelGGL(k_cost_scan, dim3(1), dim3(1), 0, stream, hist);
+	hipLaunchKernelGGL(k_cost_scatter, dim3(64), dim3(256), 0, stream, (const int *)tile_costs, n_tiles, hist, order);
 	return hipGetLastError();
 }
 

@@ -1,0 +1,60 @@
+// Micro-benchmark: issue rate of VALU instruction kinds on gfx950 (wave-instructions per cycle per SIMD).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef float f2 __attribute__((ext_vector_type(2)));
+#define REP16(x) x x x x x x x x x x x x x x x x
+template <int KIND>
+__global__ __launch_bounds__(256) void k(float *out, int iters, float seed)
+{
+	float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+	f2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, p4 = {a1, a2}, p5 = {a3, a4}, p6 = {a5, a6}, p7 = {a7, a0};
+	unsigned u0 = threadIdx.x * 3 + 1, u1 = u0 + 7, u2 = u0 + 11, u3 = u0 + 13, u4 = u0 + 17, u5 = u0 + 19, u6 = u0 + 23, u7 = u0 + 29;
+	unsigned long long w0 = u0, w1 = u1, w2 = u2, w3 = u3;
+	const float c = 1.0000001f, d = 1e-9f;
+	for (int i = 0; i < iters; ++i)
+	{
+		if (KIND == 0) { REP16(asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(d));) }
+		if (KIND == 1) { REP16(asm volatile("v_mul_f32 %0, %0, %8\n v_add_f32 %1, %1, %9\n v_mul_f32 %2, %2, %8\n v_add_f32 %3, %3, %9\n v_mul_f32 %4, %4, %8\n v_add_f32 %5, %5, %9\n v_mul_f32 %6, %6, %8\n v_add_f32 %7, %7, %9" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(d));) }
+		if (KIND == 2) { REP16(asm volatile("v_pk_fma_f32 %0, %0, %8, %9\n v_pk_fma_f32 %1, %1, %8, %9\n v_pk_fma_f32 %2, %2, %8, %9\n v_pk_fma_f32 %3, %3, %8, %9\n v_pk_fma_f32 %4, %4, %8, %9\n v_pk_fma_f32 %5, %5, %8, %9\n v_pk_fma_f32 %6, %6, %8, %9\n v_pk_fma_f32 %7, %7, %8, %9" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(p0), "v"(p1));) }
+		if (KIND == 3) { REP16(asm volatile("v_pk_mul_f32 %0, %0, %8\n v_pk_add_f32 %1, %1, %9\n v_pk_mul_f32 %2, %2, %8\n v_pk_add_f32 %3, %3, %9\n v_pk_mul_f32 %4, %4, %8\n v_pk_add_f32 %5, %5, %9\n v_pk_mul_f32 %6, %6, %8\n v_pk_add_f32 %7, %7, %9" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(p0), "v"(p1));) }
+		if (KIND == 4) { REP16(asm volatile("v_mul_u32_u24 %0, %0, %8\n v_mul_u32_u24 %1, %1, %8\n v_mul_u32_u24 %2, %2, %8\n v_mul_u32_u24 %3, %3, %8\n v_mul_u32_u24 %4, %4, %8\n v_mul_u32_u24 %5, %5, %8\n v_mul_u32_u24 %6, %6, %8\n v_mul_u32_u24 %7, %7, %8" : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(u4), "+v"(u5), "+v"(u6), "+v"(u7) : "v"(u0));) }
+		if (KIND == 5) { REP16(asm volatile("v_mul_lo_u32 %0, %0, %8\n v_mul_lo_u32 %1, %1, %8\n v_mul_lo_u32 %2, %2, %8\n v_mul_lo_u32 %3, %3, %8\n v_mul_lo_u32 %4, %4, %8\n v_mul_lo_u32 %5, %5, %8\n v_mul_lo_u32 %6, %6, %8\n v_mul_lo_u32 %7, %7, %8" : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(u4), "+v"(u5), "+v"(u6), "+v"(u7) : "v"(u0));) }
+		if (KIND == 6) { REP16(asm volatile("v_mad_u64_u32 %0, vcc, %4, %5, %0\n v_mad_u64_u32 %1, vcc, %4, %5, %1\n v_mad_u64_u32 %2, vcc, %4, %5, %2\n v_mad_u64_u32 %3, vcc, %4, %5, %3" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3) : "v"(u0), "v"(u1) : "vcc");) }
+		if (KIND == 7) { REP16(asm volatile("v_sqrt_f32 %0, %0\n v_sqrt_f32 %1, %1\n v_sqrt_f32 %2, %2\n v_sqrt_f32 %3, %3\n v_sqrt_f32 %4, %4\n v_sqrt_f32 %5, %5\n v_sqrt_f32 %6, %6\n v_sqrt_f32 %7, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));) }
+		if (KIND == 8) { REP16(asm volatile("v_cmp_lt_f32 vcc, %0, %8\n v_cndmask_b32 %1, %1, %9, vcc\n v_cmp_lt_f32 vcc, %2, %8\n v_cndmask_b32 %3, %3, %9, vcc\n v_cmp_lt_f32 vcc, %4, %8\n v_cndmask_b32 %5, %5, %9, vcc\n v_cmp_lt_f32 vcc, %6, %8\n v_cndmask_b32 %7, %7, %9, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(d) : "vcc");) }
+		if (KIND == 9) { REP16(asm volatile("v_fma_f64 %0, %0, %4, %5\n v_fma_f64 %1, %1, %4, %5\n v_fma_f64 %2, %2, %4, %5\n v_fma_f64 %3, %3, %4, %5" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3) : "v"(w0), "v"(w1));) }
+	}
+	out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p1.y + p2.x + p3.y + p4.x + p5.y + p6.x + p7.y + (float)(u0 ^ u1 ^ u2 ^ u3 ^ u4 ^ u5 ^ u6 ^ u7) + (float)(w0 ^ w1 ^ w2 ^ w3);
+}
+template <int KIND> void run(const char *name, int per_iter, int blocks_per_cu, float *out)
+{
+	const int iters = 2000;
+	hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+	int grid = 256 * blocks_per_cu;
+	hipLaunchKernelGGL(k<KIND>, dim3(grid), dim3(256), 0, 0, out, 10, 1.0f);
+	hipEventRecord(a);
+	hipLaunchKernelGGL(k<KIND>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0f);
+	hipEventRecord(b); hipEventSynchronize(b);
+	float ms; hipEventElapsedTime(&ms, a, b);
+	double insts = (double)grid * 4 /*waves*/ * iters * per_iter;       // wave-instructions
+	double per_simd_per_s = insts / (ms * 1e-3) / 1024.0;
+	printf("%-28s waves/SIMD=%d  %.2f ms  %.3f Ginst/s/SIMD  -> %.2f cycles/inst @2.4GHz\n", name, blocks_per_cu, ms, per_simd_per_s / 1e9, 2.4e9 / per_simd_per_s);
+}
+int main()
+{
+	float *out; hipMalloc(&out, sizeof(float) * 256 * 8 * 256);
+	for (int occ : {1, 2, 4}) {
+		run<0>("v_fma_f32", 128, occ, out);
+		run<1>("v_mul_f32/v_add_f32", 128, occ, out);
+		run<2>("v_pk_fma_f32", 128, occ, out);
+		run<3>("v_pk_mul_f32/v_pk_add_f32", 128, occ, out);
+		run<4>("v_mul_u32_u24", 128, occ, out);
+		run<5>("v_mul_lo_u32", 128, occ, out);
+		run<6>("v_mad_u64_u32", 64, occ, out);
+		run<7>("v_sqrt_f32", 128, occ, out);
+		run<8>("v_cmp+v_cndmask", 128, occ, out);
+		run<9>("v_fma_f64", 64, occ, out);
+	}
+	return 0;
+}
