@@ -84,7 +84,8 @@ void wbrt_calculate_camera(wbrt_camera *camera, wbrt_vec3 look_from, wbrt_vec3 l
 	wbrt_vec3 vv = mul(v, viewport_h);
 	wbrt_vec3 llc = sub(sub(sub(look_from, div(vu, 2.0f)), div(vv, 2.0f)), mul(w, focus_distance));
 
-	float defocus_radius = focus_distance * (float)std::tan((double)(aperture / 2.0f));
+	// tan() returns double there, so the product with focusDistance is formed in double (cl_camera.cpp:27)
+	float defocus_radius = (float)((double)focus_distance * std::tan((double)(aperture / 2.0f)));
 
 	camera->width = width;
 	camera->height = height;

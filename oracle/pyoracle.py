@@ -17,6 +17,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(_HERE, "liboracle.so")
 REF_SO = os.path.join(_HERE, "_ref", "libwbref.so")
+REF_HOST_SO = os.path.join(_HERE, "_ref", "libwbref_host.so")
 
 MATH_LIBM, MATH_PORTABLE = 0, 1
 OUT_MEAN, OUT_SUM = 0, 1
@@ -25,7 +26,7 @@ NUM_COUNTERS = 26
 
 def build():
     """Builds liboracle.so, and _ref/libwbref.so when the reference tree is present."""
-    subprocess.run(["make", "-C", _HERE, "oracle", "ref"], check=True)
+    subprocess.run(["make", "-C", _HERE, "oracle", "ref", "ref_host"], check=True)
 
 
 class _SceneC(C.Structure):
@@ -93,6 +94,13 @@ def ref_lib():
         l.wbref_rand_float.restype = C.c_float
         _ref = l
     return _ref
+
+
+def ref_host_lib():
+    """The reference's host-side functions (oracle/_ref/libwbref_host.so)."""
+    if not os.path.exists(REF_HOST_SO):
+        raise RuntimeError("%s missing (needs /root/reference at build time)" % REF_HOST_SO)
+    return C.CDLL(REF_HOST_SO)
 
 
 class Oracle:

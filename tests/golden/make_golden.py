@@ -183,12 +183,134 @@ def image_case(tag, scene, cam, nblocks, seed):
     save("img_%s.npz" % tag, image=img, ids=ids.astype(np.int32), meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8))
 
 
+def write_rle_hdr(path, px):
+    """Writes a Radiance RGBE file with adaptive RLE scanlines from an [h,w,3] float array."""
+    h, w, _ = px.shape
+
+    def rgbe(rgb):
+        m = float(max(rgb))
+        if m < 1e-32:
+            return (0, 0, 0, 0)
+        e = int(np.floor(np.log2(m))) + 1
+        sc = 256.0 / 2.0 ** e
+        return (int(rgb[0] * sc), int(rgb[1] * sc), int(rgb[2] * sc), e + 128)
+
+    quads = np.array([[rgbe(px[y, x]) for x in range(w)] for y in range(h)], dtype=np.uint8)
+    body = bytearray()
+    for y in range(h):
+        body += bytes([2, 2, (w >> 8) & 0xFF, w & 0xFF])
+        for comp in range(4):
+            row = quads[y, :, comp]
+            x = 0
+            while x < w:
+                run = 1
+                while x + run < w and run < 127 and row[x + run] == row[x]:
+                    run += 1
+                if run >= 3:
+                    body += bytes([128 + run, int(row[x])])
+                    x += run
+                else:
+                    lit = 1
+                    while x + lit < w and lit < 128 and not (x + lit + 2 < w and row[x + lit] == row[x + lit + 1] == row[x + lit + 2]):
+                        lit += 1
+                    body += bytes([lit]) + bytes(int(v) for v in row[x:x + lit])
+                    x += lit
+    with open(path, "wb") as f:
+        f.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (h, w) + bytes(body))
+
+
+def host_kat():
+    """Golden vectors from the reference's HOST functions (oracle/_ref/libwbref_host.so)."""
+    import tempfile
+    hl = orc.ref_host_lib()
+    cfg = (C.c_int * 5)()
+    hl.wbrefh_config(cfg)
+    assert list(cfg) == [1280, 720, 5, 32, 4]
+    f3 = lambda v: (C.c_float * 3)(*v)
+    hl.wbrefh_calculate_camera.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float]
+    rs = np.random.RandomState(17)
+    cases = [((-1.3, 0.2, 0.5), (0.2, 0.0, -1.5), (0, 1, 0), 60.0, 1.7777777, 2.0, 1.2),
+             ((0, 0, 0), (0, 0, -1), (0, 1, 0), 90.0, 1.7777777, 1.0, 0.0)]
+    for _ in range(30):
+        cases.append((tuple(rs.uniform(-3, 3, 3)), tuple(rs.uniform(-3, 3, 3)), (0, 1, 0), float(rs.uniform(20, 110)),
+                      1.7777777, float(rs.uniform(0.5, 8)), float(rs.uniform(0, 3))))
+    params = np.zeros((len(cases), 13), dtype=np.float32)
+    cams = np.zeros((len(cases), 120), dtype=np.uint8)
+    for i, (fr, at, up, fov, asp, foc, ap) in enumerate(cases):
+        params[i] = list(fr) + list(at) + list(up) + [fov, asp, foc, ap]
+        p32 = params[i]
+        cam = pkg.Camera()
+        hl.wbrefh_calculate_camera(C.byref(cam), f3(p32[0:3]), f3(p32[3:6]), f3(p32[6:9]), float(p32[9]), float(p32[10]), float(p32[11]), float(p32[12]))
+        cams[i] = np.frombuffer(bytes(cam), dtype=np.uint8)
+    # block planner at the reference's compiled-in 1280x720
+    hl.wbrefh_ideal_block_size.argtypes = [C.c_int, C.c_int, C.c_void_p]
+    targets = np.array([1, 2, 3, 4, 5, 6, 8, 9, 12, 16, 25, 64, 100, 360], dtype=np.int32)
+    blocks = np.zeros((len(targets), 2), dtype=np.int32)
+    for i, t in enumerate(targets):
+        out = (C.c_float * 3)()
+        hl.wbrefh_ideal_block_size(1280 * 720, int(t), out)
+        blocks[i] = [int(out[0]), int(out[1])]
+    # OBJ loader: the reference's triangles must equal this repo's loader bit for bit
+    hl.wbrefh_read_mesh.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    mat = pkg.material((0.8, 0.6, 0.2), 0.5, 0.0, pkg.METAL)
+    mesh_boxes = {}
+    for name in ("f1_car", "burger"):
+        path = os.path.join(REF_ASSETS, name + ".obj").encode()
+        nv, nt = C.c_int(0), C.c_int(0)
+        mn, mx = (C.c_float * 3)(), (C.c_float * 3)()
+        assert hl.wbrefh_read_mesh(path, f3((0.15, 0.15, 0.15)), f3((0.0, -0.5, -1.0)), C.byref(mat), None, 0, C.byref(nv), C.byref(nt), mn, mx) == 0
+        tris = (pkg.Triangle * nt.value)()
+        assert hl.wbrefh_read_mesh(path, f3((0.15, 0.15, 0.15)), f3((0.0, -0.5, -1.0)), C.byref(mat), tris, nt.value, C.byref(nv), C.byref(nt), mn, mx) == 0
+        mine, mmn, mmx, mnv = pkg.read_mesh(path.decode(), (0.15, 0.15, 0.15), (0.0, -0.5, -1.0), mat, 0)
+        assert mnv == nv.value and len(mine) == nt.value
+        assert bytes(mine) == bytes(tris), "OBJ loader differs from the reference for " + name
+        assert tuple(mn) == mmn.tuple() and tuple(mx) == mmx.tuple()
+        mesh_boxes[name] = np.array([list(mn), list(mx)], dtype=np.float32)
+        print(name, "reference loader == this repo's loader:", nt.value, "triangles, box", list(mn), list(mx))
+    # HDR loader + sky tone map on a synthetic RLE file (the reference's skybox.hdr is not in its checkout)
+    px = rs.uniform(0, 6, (5, 24, 3))
+    px[2, 4:17] = px[2, 4]
+    px[3] = 0.0
+    tmp = tempfile.mkdtemp()
+    hdr = os.path.join(tmp, "sky.hdr")
+    write_rle_hdr(hdr, px)
+    w, h = C.c_int(0), C.c_int(0)
+    hl.wbrefh_load_hdr.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    assert hl.wbrefh_load_hdr(hdr.encode(), C.byref(w), C.byref(h), None, None, 0) == 0
+    raw = np.zeros((h.value, w.value, 3), dtype=np.float32)
+    toned = np.zeros_like(raw)
+    assert hl.wbrefh_load_hdr(hdr.encode(), C.byref(w), C.byref(h), raw.ctypes.data_as(C.c_void_p), toned.ctypes.data_as(C.c_void_p), raw.size // 3) == 0
+    hdr_bytes = np.frombuffer(open(hdr, "rb").read(), dtype=np.uint8)
+    # WriteColour on a ladder of values
+    vals = np.concatenate([np.linspace(0, 1, 4001), rs.uniform(0, 1, 4000), (np.arange(256) / 255.0) ** 2]).astype(np.float32)
+    vals = vals[: (len(vals) // 3) * 3].reshape(-1, 3)
+    hl.wbrefh_write_colour.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    bgr = np.zeros((len(vals), 3), dtype=np.uint8)
+    for i, v in enumerate(vals):
+        out = (C.c_ubyte * 3)()
+        hl.wbrefh_write_colour(i % 720, i % 1280, f3(v), out)
+        bgr[i] = list(out)
+    # BMP writer on a 5x3 image (row padding 1 byte)
+    img = rs.randint(0, 256, (3, 5, 3)).astype(np.uint8)  # B,G,R rows bottom-up, as the reference stores it
+    bmp = os.path.join(tmp, "t.bmp")
+    hl.wbrefh_write_bmp.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p]
+    hl.wbrefh_write_bmp(img.ctypes.data_as(C.c_void_p), 3, 5, bmp.encode())
+    bmp_bytes = np.frombuffer(open(bmp, "rb").read(), dtype=np.uint8)
+    save("host_kat.npz", cam_params=params, cam_bytes=cams, block_targets=targets, blocks=blocks,
+         box_f1_car=mesh_boxes["f1_car"], box_burger=mesh_boxes["burger"], hdr_file=hdr_bytes, hdr_raw=raw, hdr_toned=toned,
+         colour_in=vals, colour_bgr=bgr, bmp_in=img, bmp_file=bmp_bytes)
+
+
 def main():
     if not orc.have_ref():
         raise SystemExit("oracle/_ref/libwbref.so missing: run `make -C oracle ref` where /root/reference exists")
     sizes = (C.c_int * 8)()
     ref.wbref_sizes(sizes)
     assert list(sizes) == [12, 24, 40, 64, 28, 120, 36, 56], list(sizes)
+    if "--host-only" in sys.argv:
+        host_kat()
+        return
+    host_kat()
     rng_kat()
     fn_kat()
     scatter_kat()
