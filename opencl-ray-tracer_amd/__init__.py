@@ -83,7 +83,7 @@ def build(force=False):
     """Compiles csrc/ into libocl_rt_amd.so with hipcc for gfx950 (cross-compiles without a GPU)."""
     if force and os.path.exists(LIB_PATH):
         os.remove(LIB_PATH)
-    subprocess.run(["make", "-C", CSRC], check=True)
+    subprocess.run(["make", "-C", CSRC, "all"], check=True)
     return LIB_PATH
 
 
