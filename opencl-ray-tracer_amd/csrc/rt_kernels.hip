@@ -359,11 +359,117 @@ __device__ __forceinline__ void spheres_exact(const SceneDev &sc, F3 o, F3 d, fl
 	}
 }
 
+// Wave-private LDS staging area for triangle tiles: two buffers of up to 64 triangles, each
+// triangle three float4 {p0.xyz e0.x | e0.yz e1.xy | e1.z - - -}, component-major so that the
+// staging writes of a wave are contiguous and the per-triangle reads are broadcasts.
+struct TriTiles { float4 v[2][3][64]; };
+
+// gpu_kernel.cl:374-391 + :489-520 + :534-555.  Triangles of a hit box are streamed through
+// LDS: every active lane of the wave loads ONE triangle of the next tile from global memory
+// (coalesced 16-byte loads, issued before the current tile is processed), the wave then walks
+// the staged tile with broadcast LDS reads.  No lane waits on a per-triangle memory access.
 template <bool STATS>
-__device__ __forceinline__ void boxes_and_triangles(const SceneDev &sc, F3 o, F3 d, float &closest, int &id, Counters<STATS> &ctr)
+__device__ __forceinline__ void boxes_and_triangles(const SceneDev &sc, TriTiles &tiles, F3 o, F3 d,
+                                                    float &closest, int &id, Counters<STATS> &ctr)
 {
 	const float tmin = 0.001f;
 	if (STATS) ctr.add(C_BBOX_TESTS, (unsigned)sc.B);
+	const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+	// lanes executing this call (live pixel streams of the wave); each stages one triangle per tile
+	const unsigned long long active = __ballot(true);
+	const int n_active = __popcll(active);
+	const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(active >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)active, 0u));
+	for (int b = 0; b < sc.B; ++b)
+	{
+		const float4 mn = sc.box_min[b], mx = sc.box_max[b];
+		float tx1 = (mn.x - o.x) * ix, tx2 = (mx.x - o.x) * ix;
+		float lo = fminf(tx1, tx2), hi = fmaxf(tx1, tx2);
+		float ty1 = (mn.y - o.y) * iy, ty2 = (mx.y - o.y) * iy;
+		lo = fmaxf(lo, fminf(ty1, ty2));
+		hi = fminf(hi, fmaxf(ty1, ty2));
+		float tz1 = (mn.z - o.z) * iz, tz2 = (mx.z - o.z) * iz;
+		lo = fmaxf(lo, fminf(tz1, tz2));
+		hi = fminf(hi, fmaxf(tz1, tz2));
+		const bool hit_box = hi > fmaxf(lo, 0.0f);
+		if (STATS && hit_box) ctr.add(C_BBOX_HITS, 1);
+		if (!__ballot(hit_box)) continue; // no lane of the wave needs this box
+		const int2 range = sc.box_range[b];
+		int buf = 0;
+		float4 n0 = make_float4(0, 0, 0, 0), n1 = n0, n2 = n0;
+		if (range.x + rank < range.y)
+		{
+			const float4 *src = sc.tri_geom + 3 * (size_t)(range.x + rank);
+			n0 = src[0]; n1 = src[1]; n2 = src[2];
+		}
+		for (int base = range.x; base < range.y; base += n_active)
+		{
+			tiles.v[buf][0][rank] = n0;
+			tiles.v[buf][1][rank] = n1;
+			tiles.v[buf][2][rank] = n2;
+			__builtin_amdgcn_wave_barrier(); // keep the staging stores ahead of the tile reads
+			const int next = base + n_active + rank;
+			if (next < range.y)
+			{
+				const float4 *src = sc.tri_geom + 3 * (size_t)next;
+				n0 = src[0]; n1 = src[1]; n2 = src[2];
+			}
+			const int count = range.y - base < n_active ? range.y - base : n_active;
+			if (hit_box)
+			{
+				for (int j = 0; j < count; ++j)
+				{
+					const float4 g0 = tiles.v[buf][0][j];
+					const float4 g1 = tiles.v[buf][1][j];
+					const float4 g2 = tiles.v[buf][2][j];
+					const F3 p0 = f3(g0.x, g0.y, g0.z), e0 = f3(g0.w, g1.x, g1.y), e1 = f3(g1.z, g1.w, g2.x);
+					if (STATS) ctr.add(C_TRI_TESTS, 1);
+					F3 h = cross(d, e1);
+					float det = dot(e0, h);
+					if (det > -0.00001f && det < 0.00001f) { if (STATS) ctr.add(C_TRI_EXIT_PARALLEL, 1); continue; }
+					float f = 1.0f / det;
+					F3 s = o - p0;
+					float u = f * dot(s, h);
+					if (u < 0.0f || u > 1.0f) { if (STATS) ctr.add(C_TRI_EXIT_U, 1); continue; }
+					F3 q = cross(s, e0);
+					float v = f * dot(d, q);
+					if (v < 0.0f || u + v > 1.0f) { if (STATS) ctr.add(C_TRI_EXIT_V, 1); continue; }
+					if (STATS) ctr.add(C_TRI_REACH_T, 1);
+					float t0 = f * dot(e1, q);
+					if (t0 > tmin && t0 < closest)
+					{
+						if (STATS) ctr.add(C_TRI_ACCEPT, 1);
+						closest = t0;
+						id = sc.S + base + j;
+					}
+				}
+			}
+			__builtin_amdgcn_wave_barrier();
+			buf ^= 1;
+		}
+	}
+}
+
+// Triangle phase for the render build: every lane of the wave (helper lanes whose own pixel
+// stream is finished included) loads ONE triangle of the current 64-triangle tile straight
+// into registers (coalesced 16-byte loads, next tile prefetched), then the rays of the lanes
+// that hit the box are broadcast one at a time (v_readlane -> scalar operands) and each lane
+// tests its triangle against that ray.  All 64 lanes work whatever the number of rays, and a
+// tile is fetched once per wave, not once per ray.  A hit posts (t, triangle index) to the
+// ray's slot in LDS with a 64-bit atomic min: the reference's sequential rule — accept
+// tMin < t0 < closest, first triangle wins ties (gpu_kernel.cl:382-387,520) — selects exactly
+// the lexicographic minimum of (t0, index) among candidates below the sphere result.
+__device__ __forceinline__ float lane_bcast(float v, int lane)
+{
+	return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+__device__ __forceinline__ void triangles_cooperative(const SceneDev &sc, unsigned long long *best, bool trace,
+                                                      F3 o, F3 d, float &closest, int &id)
+{
+	const float tmin = 0.001f;
+	const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+	best[lane] = ((unsigned long long)__float_as_uint(closest) << 32) | 0xFFFFFFFFull;
+	__builtin_amdgcn_wave_barrier();
 	const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
 	for (int b = 0; b < sc.B; ++b)
 	{
@@ -376,45 +482,65 @@ __device__ __forceinline__ void boxes_and_triangles(const SceneDev &sc, F3 o, F3
 		float tz1 = (mn.z - o.z) * iz, tz2 = (mx.z - o.z) * iz;
 		lo = fmaxf(lo, fminf(tz1, tz2));
 		hi = fminf(hi, fmaxf(tz1, tz2));
-		if (!(hi > fmaxf(lo, 0.0f))) continue;
-		if (STATS) ctr.add(C_BBOX_HITS, 1);
+		const unsigned long long rays = __ballot(trace && hi > fmaxf(lo, 0.0f));
+		if (!rays) continue;
 		const int2 range = sc.box_range[b];
-		for (int j = range.x; j < range.y; ++j)
+		float4 n0 = make_float4(0, 0, 0, 0), n1 = n0, n2 = n0;
+		if (range.x + lane < range.y)
 		{
-			const float4 g0 = sc.tri_geom[3 * j + 0];
-			const float4 g1 = sc.tri_geom[3 * j + 1];
-			const float4 g2 = sc.tri_geom[3 * j + 2];
-			const F3 p0 = f3(g0.x, g0.y, g0.z), e0 = f3(g0.w, g1.x, g1.y), e1 = f3(g1.z, g1.w, g2.x);
-			if (STATS) ctr.add(C_TRI_TESTS, 1);
-			F3 h = cross(d, e1);
-			float det = dot(e0, h);
-			if (det > -0.00001f && det < 0.00001f) { if (STATS) ctr.add(C_TRI_EXIT_PARALLEL, 1); continue; }
-			float f = 1.0f / det;
-			F3 s = o - p0;
-			float u = f * dot(s, h);
-			if (u < 0.0f || u > 1.0f) { if (STATS) ctr.add(C_TRI_EXIT_U, 1); continue; }
-			F3 q = cross(s, e0);
-			float v = f * dot(d, q);
-			if (v < 0.0f || u + v > 1.0f) { if (STATS) ctr.add(C_TRI_EXIT_V, 1); continue; }
-			if (STATS) ctr.add(C_TRI_REACH_T, 1);
-			float t0 = f * dot(e1, q);
-			if (t0 > tmin && t0 < closest)
+			const float4 *src = sc.tri_geom + 3 * (size_t)(range.x + lane);
+			n0 = src[0]; n1 = src[1]; n2 = src[2];
+		}
+		for (int base = range.x; base < range.y; base += 64)
+		{
+			const float4 g0 = n0, g1 = n1, g2 = n2;
+			const int tri = base + lane;
+			const bool have = tri < range.y;
+			if (tri + 64 < range.y)
 			{
-				if (STATS) ctr.add(C_TRI_ACCEPT, 1);
-				closest = t0;
-				id = sc.S + j;
+				const float4 *src = sc.tri_geom + 3 * (size_t)(tri + 64);
+				n0 = src[0]; n1 = src[1]; n2 = src[2];
+			}
+			const F3 p0 = f3(g0.x, g0.y, g0.z), e0 = f3(g0.w, g1.x, g1.y), e1 = f3(g1.z, g1.w, g2.x);
+			for (unsigned long long m = rays; m; m &= m - 1)
+			{
+				const int r = __builtin_ctzll(m);
+				const F3 ro = f3(lane_bcast(o.x, r), lane_bcast(o.y, r), lane_bcast(o.z, r));
+				const F3 rd = f3(lane_bcast(d.x, r), lane_bcast(d.y, r), lane_bcast(d.z, r));
+				const float rc = lane_bcast(closest, r);
+				if (!have) continue;
+				F3 h = cross(rd, e1);
+				float det = dot(e0, h);
+				if (det > -0.00001f && det < 0.00001f) continue;
+				float f = 1.0f / det;
+				F3 s = ro - p0;
+				float u = f * dot(s, h);
+				if (u < 0.0f || u > 1.0f) continue;
+				F3 q = cross(s, e0);
+				float v = f * dot(rd, q);
+				if (v < 0.0f || u + v > 1.0f) continue;
+				float t0 = f * dot(e1, q);
+				if (t0 > tmin && t0 < rc)
+					atomicMin(&best[r], ((unsigned long long)__float_as_uint(t0) << 32) | (unsigned)tri);
 			}
 		}
+	}
+	__builtin_amdgcn_wave_barrier();
+	const unsigned long long k = best[lane];
+	if (trace && (unsigned)k != 0xFFFFFFFFu)
+	{
+		closest = __uint_as_float((unsigned)(k >> 32));
+		id = sc.S + (int)(unsigned)k;
 	}
 }
 
 // The counting build always takes the exact sphere loop: its counters are defined by the
 // reference's sequential order of decisions.
 template <bool STATS>
-__device__ __forceinline__ int closest_hit(const SceneDev &sc, F3 o, F3 d, float &t_out, Counters<STATS> &ctr)
+__device__ __forceinline__ void closest_sphere(const SceneDev &sc, F3 o, F3 d, float &closest, int &id, Counters<STATS> &ctr)
 {
-	float closest = INFINITY;
-	int id = -1;
+	closest = INFINITY;
+	id = -1;
 	const float a = dot(d, d);
 	if (STATS)
 	{
@@ -423,9 +549,6 @@ __device__ __forceinline__ int closest_hit(const SceneDev &sc, F3 o, F3 d, float
 	}
 	else if (!spheres_fast(sc, o, d, a, closest, id))
 		spheres_exact<STATS>(sc, o, d, a, closest, id, ctr);
-	if (sc.B > 0) boxes_and_triangles<STATS>(sc, o, d, closest, id, ctr);
-	t_out = closest;
-	return id;
 }
 
 // gpu_kernel.cl:182-196
@@ -521,9 +644,16 @@ __device__ __forceinline__ void init_lane(const RenderParams &p, Lane &L, int gi
 	L.sample = 0;
 }
 
-template <bool STATS>
+// MESH selects the loop shape.  Without bounding boxes a lane simply leaves the loop when its
+// pixel stream is finished.  With boxes, finished lanes stay in the loop as helpers of the
+// cooperative triangle phase (which runs in wave-uniform control flow) until the whole wave is
+// done: what bounds a mesh frame is its longest pixel stream, and a lone live lane still gets
+// all 64 lanes of triangle throughput this way.
+template <bool STATS, bool MESH>
 __global__ __launch_bounds__(256) void k_render(const RenderParams p)
 {
+	__shared__ TriTiles s_tiles[MESH && STATS ? 4 : 1]; // counting build: sequential staged loop, one per wave
+	__shared__ unsigned long long s_best[MESH && !STATS ? 4 : 1][64];
 	Counters<STATS> ctr;
 	const SceneDev &sc = p.sc;
 	long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -553,22 +683,41 @@ __global__ __launch_bounds__(256) void k_render(const RenderParams p)
 	}
 
 	int iterations = 0;
-	while (alive) // lanes of a wave leave together only when all are done; others idle
+	for (;;)
 	{
-		++iterations;
+		if (MESH ? !__ballot(alive) : !alive) break;
 		// 0 = path continues, 1 = ended black, 2 = ended on the sky, 3 = ended with `col`
 		int outcome = 0;
 		F3 col = f3(0.0f, 0.0f, 0.0f);
-		if (L.depth >= p.max_depth) // gpu_kernel.cl:276,337-340
+		bool trace = false;
+		float t = INFINITY;
+		int id = -1;
+		if (!MESH || alive)
 		{
-			outcome = (L.depth == p.max_depth) ? 1 : 2;
-			if (STATS && outcome == 1) ctr.add(C_DEPTH_EXHAUSTED, 1);
+			++iterations;
+			if (L.depth >= p.max_depth) // gpu_kernel.cl:276,337-340
+			{
+				outcome = (L.depth == p.max_depth) ? 1 : 2;
+				if (STATS && outcome == 1) ctr.add(C_DEPTH_EXHAUSTED, 1);
+			}
+			else
+			{
+				trace = true;
+				if (STATS) ctr.add(C_SEGMENTS, 1);
+				closest_sphere<STATS>(sc, L.o, L.d, t, id, ctr);
+			}
 		}
-		else
+		if (MESH)
 		{
-			float t;
-			if (STATS) ctr.add(C_SEGMENTS, 1);
-			int id = closest_hit<STATS>(sc, L.o, L.d, t, ctr);
+			if (STATS)
+			{
+				if (trace) boxes_and_triangles<STATS>(sc, s_tiles[threadIdx.x >> 6], L.o, L.d, t, id, ctr);
+			}
+			else triangles_cooperative(sc, s_best[threadIdx.x >> 6], trace, L.o, L.d, t, id);
+		}
+		if (MESH && !alive) continue;
+		if (trace)
+		{
 			if (id < 0) outcome = 2;
 			else
 			{
@@ -738,6 +887,7 @@ __global__ __launch_bounds__(256) void k_render(const RenderParams p)
 // Primary-hit primitive id of sample 0's first segment, in the caller's numbering.
 __global__ __launch_bounds__(256) void k_primary_ids(const RenderParams p)
 {
+	__shared__ TriTiles s_tiles[4];
 	Counters<false> ctr;
 	long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
 	int gid, bx, by;
@@ -746,7 +896,9 @@ __global__ __launch_bounds__(256) void k_primary_ids(const RenderParams p)
 	init_lane(p, L, gid, bx, by);
 	camera_ray<false>(p, L, ctr);
 	float t;
-	int id = closest_hit<false>(p.sc, L.o, L.d, t, ctr);
+	int id;
+	closest_sphere<false>(p.sc, L.o, L.d, t, id, ctr);
+	if (p.sc.B > 0) boxes_and_triangles<false>(p.sc, s_tiles[threadIdx.x >> 6], L.o, L.d, t, id, ctr);
 	if (id >= p.sc.S) id = p.sc.S + p.sc.tri_orig[id - p.sc.S];
 	const int row = gid / p.bsx + p.bsy * by, colx = gid % p.bsx + p.bsx * bx;
 	p.ids[(size_t)row * p.out_w + colx] = id;
@@ -857,13 +1009,15 @@ inline unsigned grid_for(const RenderParams &p)
 
 hipError_t wbrt_launch_render(const RenderParams &p, hipStream_t stream)
 {
-	hipLaunchKernelGGL(k_render<false>, dim3(grid_for(p)), dim3(256), 0, stream, p);
+	if (p.sc.B > 0) hipLaunchKernelGGL((k_render<false, true>), dim3(grid_for(p)), dim3(256), 0, stream, p);
+	else hipLaunchKernelGGL((k_render<false, false>), dim3(grid_for(p)), dim3(256), 0, stream, p);
 	return hipGetLastError();
 }
 
 hipError_t wbrt_launch_count(const RenderParams &p, hipStream_t stream)
 {
-	hipLaunchKernelGGL(k_render<true>, dim3(grid_for(p)), dim3(256), 0, stream, p);
+	if (p.sc.B > 0) hipLaunchKernelGGL((k_render<true, true>), dim3(grid_for(p)), dim3(256), 0, stream, p);
+	else hipLaunchKernelGGL((k_render<true, false>), dim3(grid_for(p)), dim3(256), 0, stream, p);
 	return hipGetLastError();
 }
 
