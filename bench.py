@@ -69,6 +69,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", choices=["readme", "mesh"], default="readme",
+                    help="readme = headline (BASELINE.json configs[1]); mesh = configs[2]: main.cpp spheres + f1_car mesh, "
+                         "1920x1080, 100 spp (several seconds per frame)")
     args = ap.parse_args()
 
     import torch
@@ -85,8 +88,20 @@ def main():
 
     pkg = entry.load_package()
     mg = __import__("importlib").import_module(entry.PKG_NAME + ".multi_gpu")
-    scene = pkg.scene_readme()
-    cam = pkg.camera_readme(WIDTH, SPP, DEPTH)
+    spp = SPP
+    if args.config == "mesh":
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from util import scene_main_cpp_with_mesh  # builds the scene from the committed triangle soup
+        scene = scene_main_cpp_with_mesh("f1_car")
+        spp = 100
+        cam = pkg.camera_main_cpp(1920, spp, DEPTH)
+        workload = ("main.cpp scene: 8 spheres + f1_car mesh (15329 triangles, 1 bounding box), 1920x1080, 100 spp per GPU shard, "
+                    "depth 50, 4 blocks of 960x540 (BASELINE.json configs[2])")
+    else:
+        scene = pkg.scene_readme()
+        cam = pkg.camera_readme(WIDTH, SPP, DEPTH)
+        workload = ("README 5-sphere scene, 1280x720, 250 spp per GPU shard, depth 50, 4 blocks of 640x360, "
+                    "bit-matched 48-bit LCG streams (BASELINE.json configs[1])")
     bw, bh = pkg.set_blocks(cam, BLOCKS)
     seeds = pkg.make_seeds(bw * bh, BASE_SEED, shard=rank)  # rank r renders seed shard r
 
@@ -97,7 +112,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
-        mg.render_step(ctx, cam, frame, total_spp=SPP * world, stream=stream,
+        mg.render_step(ctx, cam, frame, total_spp=spp * world, stream=stream,
                        all_reduce=(lambda t: dist.all_reduce(t)) if world > 1 else None)
 
     def barrier():
@@ -122,7 +137,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    paths_per_step = cam.width * cam.height * SPP * world
+    paths_per_step = cam.width * cam.height * spp * world
     result = None
     if rank == 0:
         counters = ctx.count_events(cam)  # exact event counts of this rank's launch (untimed)
@@ -135,8 +150,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": "README 5-sphere scene, 1280x720, 250 spp per GPU shard, depth 50, 4 blocks of 640x360, "
-                            "bit-matched 48-bit LCG streams (BASELINE.json configs[1])",
+                "workload": workload,
                 "paths_per_step": paths_per_step, "parallelism": "spp-shard x%d + all-reduce(sum) of the %.2f MB accumulation buffer" % (world, cam.width * cam.height * 12 / 1e6),
                 "kernel_ms_per_launch": round(k_ms, 4),
                 "readme_published_gpu_frame_s": 0.38,
@@ -144,11 +158,13 @@ def main():
             "roofline": {
                 "bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4), "traffic": None,
-                "flops_per_launch": flops, "flop_per_path": round(flops / (cam.width * cam.height * SPP), 2),
+                "flops_per_launch": flops, "flop_per_path": round(flops / (cam.width * cam.height * spp), 2),
                 "note": "FP32 vector peak assumes packed FMA; bit-exact unfused scalar code tops out at 1/4 of it",
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if args.config == "mesh":
+            result["config"].pop("readme_published_gpu_frame_s", None)
+        if world == 1 and not args.no_cpu_baseline and args.config == "readme":
             result["cpu_baseline"] = cpu_baseline(pkg, scene, cam, seeds)
         print(json.dumps(result), flush=True)
     ctx.close()
