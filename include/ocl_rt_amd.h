@@ -129,6 +129,22 @@ int wbrt_tonemap_device(wbrt_context *ctx, const void *device_image, float scale
 
 int wbrt_synchronize(wbrt_context *ctx);
 
+/* How the render kernel finds the nearest triangle of a bounding box whose slab test
+ * passed (gpu_kernel.cl:374-391).  No counterpart in the reference, which always loops.
+ *   WBRT_MESH_LOOP        every triangle of the box is tested, as the reference does;
+ *   WBRT_MESH_BVH_STRICT  a hierarchy of boxes built on upload is walked; a subtree is
+ *                         skipped only if a forward error bound of the reference's float
+ *                         triangle test (at its own |det| >= 1e-5 cutoff) proves that none
+ *                         of its triangles can be accepted: same result as the loop;
+ *   WBRT_MESH_BVH         (default) as above with the box margin capped at 1e-4 of the
+ *                         ray's distance to the mesh.  Differs from the loop only for a ray
+ *                         within about one degree of a triangle's plane that passes that
+ *                         triangle at more than the margin: there the reference's own
+ *                         accept/reject decision is rounding noise.
+ * Primary ids and event counters always use the loop.  Takes effect at the next render. */
+enum { WBRT_MESH_LOOP = 0, WBRT_MESH_BVH_STRICT = 1, WBRT_MESH_BVH = 2 };
+int wbrt_set_mesh_mode(wbrt_context *ctx, int mode);
+
 /* kernel-only timing: when enabled every render launch is bracketed by HIP events on
  * its own stream.  wbrt_get_timing synchronises and returns the sum over launches since
  * the last reset. */

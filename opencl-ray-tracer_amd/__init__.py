@@ -88,6 +88,7 @@ def build(force=False):
 
 
 _lib = None
+MESH_LOOP, MESH_BVH_STRICT, MESH_BVH = 0, 1, 2
 
 # name -> (restype, argtypes); every symbol declared in include/ocl_rt_amd.h
 _P = C.c_void_p
@@ -105,6 +106,7 @@ _SIGNATURES = {
     "wbrt_count_events_frame": (C.c_int, [_P, C.POINTER(Camera), _P]),
     "wbrt_tonemap_device": (C.c_int, [_P, _P, C.c_float, C.c_int32, C.c_int32, _P, _P]),
     "wbrt_synchronize": (C.c_int, [_P]),
+    "wbrt_set_mesh_mode": (C.c_int, [_P, C.c_int]),
     "wbrt_set_timing": (C.c_int, [_P, C.c_int]),
     "wbrt_get_timing": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_int]),
     "wbrt_device_info": (C.c_int, [_P, C.c_char_p, C.c_size_t]),
@@ -412,6 +414,10 @@ class Context:
 
     def synchronize(self):
         _check(lib().wbrt_synchronize(self._h))
+
+    def set_mesh_mode(self, mode):
+        """MESH_LOOP, MESH_BVH_STRICT or MESH_BVH (default); see include/ocl_rt_amd.h."""
+        _check(lib().wbrt_set_mesh_mode(self._h, int(mode)))
 
     def set_timing(self, on=True):
         _check(lib().wbrt_set_timing(self._h, 1 if on else 0))

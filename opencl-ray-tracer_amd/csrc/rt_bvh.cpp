@@ -1,0 +1,216 @@
+// Host-side builder of the triangle hierarchies the render kernel walks.
+//
+// The reference tests every triangle of a bounding box whose slab test passes
+// (gpu_kernel.cl:374-391) and keeps the nearest accepted hit, first triangle winning ties
+// (gpu_kernel.cl:520).  The winner of that loop is the lexicographic minimum of
+// (t0, position in the loop) over the triangles its Moller-Trumbore test accepts, so any
+// visiting order that reaches every triangle the test COULD accept gives the same answer.
+// One binary hierarchy of axis-aligned boxes per bounding box lets the kernel skip the rest.
+//
+// What "could accept" means is decided by the float arithmetic of gpu_kernel.cl:489-520, not
+// by geometry: with u = 2^-24 and |det| >= 1e-5 (the test's own parallel cutoff) a forward
+// error analysis of that code bounds the distance between an accepted hit and the triangle
+// by about 29u/1e-5 * (|o-p0| + |e|) * |d| * |e0||e1|.  Nodes therefore carry
+// E = max |e0||e1| of their triangles and the kernel widens each box per ray by
+// 0.35 * E * R * |d| (R bounds |o-p0| + |e|); when E*|d| is so large that the rounding of det
+// itself is comparable with the cutoff the node is always visited.
+#include "rt_device.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+
+namespace {
+
+struct Bounds
+{
+	double mn[3], mx[3];
+	void reset() { for (int a = 0; a < 3; ++a) { mn[a] = DBL_MAX; mx[a] = -DBL_MAX; } }
+	void add(const double p[3]) { for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], p[a]); mx[a] = std::max(mx[a], p[a]); } }
+	void add(const Bounds &b) { for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], b.mn[a]); mx[a] = std::max(mx[a], b.mx[a]); } }
+	double area() const
+	{
+		double x = mx[0] - mn[0], y = mx[1] - mn[1], z = mx[2] - mn[2];
+		if (x < 0 || y < 0 || z < 0) return 0.0;
+		return 2.0 * (x * y + y * z + z * x);
+	}
+};
+
+struct Prim
+{
+	Bounds b;
+	double c[3]; // centroid of the bounds
+	double e;    // |e0||e1|
+	int index;   // position in the grouped triangle order
+};
+
+float round_down(double v) { float f = (float)v; return (double)f > v ? std::nextafterf(f, -INFINITY) : f; }
+float round_up(double v) { float f = (float)v; return (double)f < v ? std::nextafterf(f, INFINITY) : f; }
+
+struct Builder
+{
+	std::vector<Prim> prims;
+	WbrtBvh *out;
+	bool median_only;
+	int max_depth = 0;
+
+	static constexpr int kLeaf = 4, kBins = 16;
+
+	int make_leaf(int first, int count)
+	{
+		const int base = (int)out->tri_index.size();
+		for (int i = 0; i < count; ++i) out->tri_index.push_back(prims[(size_t)first + i].index);
+		return ~((base << 4) | (count - 1));
+	}
+
+	// returns the child reference of the subtree over prims[first, first+count)
+	int build(int first, int count, int depth, Bounds &bounds, double &emax)
+	{
+		max_depth = std::max(max_depth, depth);
+		bounds.reset();
+		emax = 0.0;
+		Bounds cb;
+		cb.reset();
+		for (int i = first; i < first + count; ++i)
+		{
+			bounds.add(prims[(size_t)i].b);
+			cb.add(prims[(size_t)i].c);
+			emax = std::max(emax, prims[(size_t)i].e);
+		}
+		if (count <= kLeaf) return make_leaf(first, count);
+
+		int axis = 0;
+		for (int a = 1; a < 3; ++a) if (cb.mx[a] - cb.mn[a] > cb.mx[axis] - cb.mn[axis]) axis = a;
+		int mid = -1;
+		const double extent = cb.mx[axis] - cb.mn[axis];
+		if (!median_only && extent > 0.0 && std::isfinite(extent))
+		{
+			// binned surface-area heuristic on the widest centroid axis
+			Bounds bin_b[kBins];
+			int bin_n[kBins];
+			for (int k = 0; k < kBins; ++k) { bin_b[k].reset(); bin_n[k] = 0; }
+			auto bin_of = [&](const Prim &p) {
+				int k = (int)((p.c[axis] - cb.mn[axis]) / extent * kBins);
+				return std::min(std::max(k, 0), kBins - 1);
+			};
+			for (int i = first; i < first + count; ++i)
+			{
+				int k = bin_of(prims[(size_t)i]);
+				bin_b[k].add(prims[(size_t)i].b);
+				bin_n[k]++;
+			}
+			double right_area[kBins];
+			Bounds acc;
+			acc.reset();
+			for (int k = kBins - 1; k > 0; --k) { acc.add(bin_b[k]); right_area[k] = acc.area(); }
+			acc.reset();
+			double best = DBL_MAX;
+			int best_k = -1, nl = 0;
+			for (int k = 0; k < kBins - 1; ++k)
+			{
+				acc.add(bin_b[k]);
+				nl += bin_n[k];
+				const int nr = count - nl;
+				if (!nl || !nr) continue;
+				const double cost = acc.area() * nl + right_area[k + 1] * nr;
+				if (cost < best) { best = cost; best_k = k; }
+			}
+			if (best_k >= 0)
+			{
+				auto it = std::partition(prims.begin() + first, prims.begin() + first + count,
+				                         [&](const Prim &p) { return bin_of(p) <= best_k; });
+				mid = (int)(it - prims.begin());
+				if (mid == first || mid == first + count) mid = -1;
+			}
+		}
+		if (mid < 0)
+		{
+			// object median; ties broken by index so that the split always has two sides
+			mid = first + count / 2;
+			std::nth_element(prims.begin() + first, prims.begin() + mid, prims.begin() + first + count,
+			                 [&](const Prim &a, const Prim &b) {
+				                 if (a.c[axis] != b.c[axis]) return a.c[axis] < b.c[axis];
+				                 return a.index < b.index;
+			                 });
+		}
+		const size_t node = out->nodes.size();
+		out->nodes.emplace_back();
+		Bounds lb, rb;
+		double le, re;
+		const int left = build(first, mid - first, depth + 1, lb, le);
+		const int right = build(mid, first + count - mid, depth + 1, rb, re);
+		WbrtBvhNode n;
+		for (int a = 0; a < 3; ++a)
+		{
+			n.lmin[a] = round_down(lb.mn[a]); n.lmax[a] = round_up(lb.mx[a]);
+			n.rmin[a] = round_down(rb.mn[a]); n.rmax[a] = round_up(rb.mx[a]);
+		}
+		n.left = left; n.right = right;
+		n.le = round_up(le * 1.000001); n.re = round_up(re * 1.000001);
+		out->nodes[node] = n;
+		return (int)node;
+	}
+};
+
+} // namespace
+
+// tri_geom: the grouped triangle array of the device scene (3 float4 per triangle: p0.xyz e0.x |
+// e0.yz e1.xy | e1.z - - -); ranges[b] = [first, last) of box b.  Node and leaf indices are
+// global over all boxes.
+void wbrt_build_bvh(const float4 *tri_geom, const int2 *ranges, int B, WbrtBvh &bvh)
+{
+	bvh.nodes.clear();
+	bvh.tri_index.clear();
+	bvh.roots.assign((size_t)B, WbrtBvhRoot{});
+	bvh.depth = 0;
+	for (int b = 0; b < B; ++b)
+	{
+		WbrtBvhRoot &root = bvh.roots[(size_t)b];
+		const int first = ranges[b].x, count = ranges[b].y - ranges[b].x;
+		root.ref = 0; root.empty = 1;
+		if (count <= 0) continue;
+		std::vector<Prim> prims((size_t)count);
+		for (int i = 0; i < count; ++i)
+		{
+			const float4 g0 = tri_geom[3 * (size_t)(first + i)], g1 = tri_geom[3 * (size_t)(first + i) + 1], g2 = tri_geom[3 * (size_t)(first + i) + 2];
+			const double p0[3] = { g0.x, g0.y, g0.z };
+			const double e0[3] = { g0.w, g1.x, g1.y }, e1[3] = { g1.z, g1.w, g2.x };
+			double p1[3], p2[3];
+			for (int a = 0; a < 3; ++a) { p1[a] = p0[a] + e0[a]; p2[a] = p0[a] + e1[a]; }
+			Prim &p = prims[(size_t)i];
+			p.b.reset(); p.b.add(p0); p.b.add(p1); p.b.add(p2);
+			for (int a = 0; a < 3; ++a)
+			{
+				// NaN or infinite vertices: an unbounded box keeps the triangle reachable
+				if (!std::isfinite(p.b.mn[a]) || !std::isfinite(p.b.mx[a]) || p.b.mn[a] > p.b.mx[a]) { p.b.mn[a] = -DBL_MAX; p.b.mx[a] = DBL_MAX; }
+				p.c[a] = 0.5 * p.b.mn[a] + 0.5 * p.b.mx[a];
+			}
+			p.e = std::sqrt(e0[0] * e0[0] + e0[1] * e0[1] + e0[2] * e0[2]) * std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+			if (!std::isfinite(p.e)) p.e = DBL_MAX;
+			p.index = first + i;
+		}
+		for (int attempt = 0; attempt < 2; ++attempt)
+		{
+			const size_t nodes_before = bvh.nodes.size(), tris_before = bvh.tri_index.size();
+			Builder bl;
+			bl.prims = prims;
+			bl.out = &bvh;
+			bl.median_only = attempt == 1;
+			Bounds rb;
+			double re;
+			root.ref = bl.build(0, count, 0, rb, re);
+			if (bl.max_depth < WBRT_BVH_STACK || attempt == 1)
+			{
+				for (int a = 0; a < 3; ++a) { root.mn[a] = round_down(rb.mn[a]); root.mx[a] = round_up(rb.mx[a]); }
+				root.e = round_up(re * 1.000001);
+				root.empty = 0;
+				bvh.depth = std::max(bvh.depth, bl.max_depth);
+				break;
+			}
+			// a surface-area tree deeper than the kernel's stack: rebuild balanced
+			bvh.nodes.resize(nodes_before);
+			bvh.tri_index.resize(tris_before);
+		}
+	}
+}

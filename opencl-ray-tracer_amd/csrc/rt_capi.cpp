@@ -64,7 +64,9 @@ struct wbrt_context
 	hipStream_t stream = nullptr; // used by the blocking entry points
 	DevBuf sph_geom, sph_radius, sph_mat_a, sph_mat_b;
 	DevBuf tri_geom, tri_mat_a, tri_mat_b, tri_orig;
-	DevBuf box_min, box_max, box_range;
+	DevBuf box_min, box_max, box_range, bvh_nodes, bvh_tris, bvh_roots;
+	int mesh_mode = WBRT_MESH_BVH;
+	float bvh_rho = 1e-4f; // WBRT_MESH_BVH: box margin as a fraction of the ray's distance bound
 	DevBuf sky, seeds, image, ids, counters, rgb8, costs, tile_costs, order, hist;
 	int lpt = 1;        // longest-first scheduling from a pilot pass
 	int pilot_spp = 4;
@@ -124,6 +126,8 @@ int make_params(wbrt_context *ctx, const wbrt_camera *cam, bool whole_frame, Ren
 	}
 	p.seeds = (const uint32_t *)ctx->seeds.p;
 	p.sc = ctx->sc;
+	if (ctx->mesh_mode == WBRT_MESH_LOOP) p.sc.bvh_nodes = nullptr;
+	p.sc.bvh_rho = ctx->mesh_mode == WBRT_MESH_BVH ? ctx->bvh_rho : 0.0f;
 	return WBRT_OK;
 }
 
@@ -188,6 +192,8 @@ int wbrt_create(int device_ordinal, wbrt_context **out)
 	if (e != hipSuccess) { delete ctx; return fail(WBRT_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorName(e)); }
 	// tuning knobs for experiments (not part of the ABI contract)
 	if (const char *v = std::getenv("WBRT_LPT")) ctx->lpt = std::atoi(v) != 0;
+	if (const char *v = std::getenv("WBRT_MESH_MODE")) { int m = std::atoi(v); if (m >= 0 && m <= 2) ctx->mesh_mode = m; }
+	if (const char *v = std::getenv("WBRT_BVH_RHO")) { float r = (float)std::atof(v); if (r > 0.0f) ctx->bvh_rho = r; }
 	if (const char *v = std::getenv("WBRT_PILOT_SPP")) ctx->pilot_spp = std::atoi(v) > 0 ? std::atoi(v) : 4;
 	*out = ctx;
 	return WBRT_OK;
@@ -201,7 +207,7 @@ int wbrt_destroy(wbrt_context *ctx)
 	for (auto &ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
 	DevBuf *all[] = { &ctx->sph_geom, &ctx->sph_radius, &ctx->sph_mat_a, &ctx->sph_mat_b, &ctx->tri_geom,
 	                  &ctx->tri_mat_a, &ctx->tri_mat_b, &ctx->tri_orig, &ctx->box_min, &ctx->box_max,
-	                  &ctx->box_range, &ctx->sky, &ctx->seeds, &ctx->image, &ctx->ids, &ctx->counters, &ctx->rgb8,
+	                  &ctx->box_range, &ctx->bvh_nodes, &ctx->bvh_tris, &ctx->bvh_roots, &ctx->sky, &ctx->seeds, &ctx->image, &ctx->ids, &ctx->counters, &ctx->rgb8,
 	                  &ctx->costs, &ctx->tile_costs, &ctx->order, &ctx->hist };
 	for (DevBuf *b : all) b->release();
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -275,8 +281,43 @@ int wbrt_upload_scene(wbrt_context *ctx, const wbrt_sphere *spheres, int32_t S,
 	UP(sph_geom, geom); UP(sph_radius, radius); UP(sph_mat_a, mat_a); UP(sph_mat_b, mat_b);
 	UP(tri_geom, tgeom); UP(tri_mat_a, tmat_a); UP(tri_mat_b, tmat_b); UP(tri_orig, torig);
 	UP(box_min, bmin); UP(box_max, bmax); UP(box_range, brange);
+	// triangle hierarchies (render build only; the counting and primary-id builds keep the loop)
+	WbrtBvh bvh;
+	std::vector<float4> bnodes, btris, broots;
+	if (Tg > 0)
+	{
+		wbrt_build_bvh(tgeom.data(), brange.data(), B, bvh);
+		static_assert(sizeof(WbrtBvhNode) == 4 * sizeof(float4), "node layout");
+		bnodes.resize(bvh.nodes.size() * 4);
+		if (!bvh.nodes.empty()) std::memcpy(bnodes.data(), bvh.nodes.data(), bvh.nodes.size() * sizeof(WbrtBvhNode));
+		btris.resize(bvh.tri_index.size() * 3);
+		for (size_t k = 0; k < bvh.tri_index.size(); ++k)
+		{
+			const size_t src = (size_t)bvh.tri_index[k];
+			btris[3 * k + 0] = tgeom[3 * src + 0];
+			btris[3 * k + 1] = tgeom[3 * src + 1];
+			float4 last = tgeom[3 * src + 2];
+			const int pos = bvh.tri_index[k];
+			std::memcpy(&last.y, &pos, 4);
+			btris[3 * k + 2] = last;
+		}
+		broots.resize((size_t)B * 2);
+		for (int b = 0; b < B; ++b)
+		{
+			const WbrtBvhRoot &r = bvh.roots[(size_t)b];
+			float ref; std::memcpy(&ref, &r.ref, 4);
+			broots[2 * (size_t)b] = make_float4(r.mn[0], r.mn[1], r.mn[2], ref);
+			broots[2 * (size_t)b + 1] = make_float4(r.mx[0], r.mx[1], r.mx[2], r.empty ? -1.0f : r.e);
+		}
+		UP(bvh_nodes, bnodes); UP(bvh_tris, btris); UP(bvh_roots, broots);
+	}
 #undef UP
 	SceneDev &sc = ctx->sc;
+	const bool have_bvh = Tg > 0;
+	sc.bvh_nodes = have_bvh ? (const float4 *)ctx->bvh_nodes.p : nullptr;
+	sc.bvh_tris = have_bvh ? (const float4 *)ctx->bvh_tris.p : nullptr;
+	sc.bvh_roots = have_bvh ? (const float4 *)ctx->bvh_roots.p : nullptr;
+	sc.bvh_rho = 0.0f;
 	sc.sph_geom = (const float4 *)ctx->sph_geom.p; sc.sph_radius = (const float *)ctx->sph_radius.p;
 	sc.sph_mat_a = (const float4 *)ctx->sph_mat_a.p; sc.sph_mat_b = (const float2 *)ctx->sph_mat_b.p;
 	sc.S = S;
@@ -423,6 +464,14 @@ int wbrt_synchronize(wbrt_context *ctx)
 	int rc = bind(ctx);
 	if (rc) return rc;
 	HIP_TRY(hipDeviceSynchronize());
+	return WBRT_OK;
+}
+
+int wbrt_set_mesh_mode(wbrt_context *ctx, int mode)
+{
+	if (!ctx) return fail(WBRT_ERR_INVALID, "null context");
+	if (mode < WBRT_MESH_LOOP || mode > WBRT_MESH_BVH) return fail(WBRT_ERR_INVALID, "bad mesh mode");
+	ctx->mesh_mode = mode;
 	return WBRT_OK;
 }
 

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <vector>
 
 #define WBRT_NUM_COUNTERS 26
 
@@ -40,6 +41,11 @@ struct SceneDev
 	const float4 *box_max;    // [B] max.xyz, 0
 	const int2   *box_range;  // [B] first, last+1 into the grouped triangle arrays
 	int B;
+	// triangle hierarchies, one per bounding box (absent: bvh_nodes == nullptr)
+	const float4 *bvh_nodes;  // 4 per node: lmin.xyz lmax.x | lmax.yz rmin.xy | rmin.z rmax.xyz | left right E_left E_right
+	const float4 *bvh_tris;   // 3 per leaf slot: tri_geom layout, fourth word of the last float4 = position in the grouped order
+	const float4 *bvh_roots;  // 2 per box: min.xyz ref | max.xyz E   (E < 0: box without triangles)
+	float bvh_rho;
 	// sky: skyw*skyh texels + skyw+1 zero guard texels, 3 floats each
 	const float *sky;
 	int skyw, skyh;
@@ -66,6 +72,29 @@ struct RenderParams
 	const uint32_t *seeds;
 	SceneDev sc;
 };
+
+// Binary hierarchy over the triangles of every bounding box.  A child reference >= 0 names a
+// node; < 0 names a leaf: ~ref = (first leaf slot << 4) | (triangles - 1).
+#define WBRT_BVH_STACK 32
+struct WbrtBvhNode
+{
+	float lmin[3], lmax[3], rmin[3], rmax[3];
+	int left, right;
+	float le, re; // max |e0||e1| over the triangles below each child
+};
+struct WbrtBvhRoot
+{
+	float mn[3], mx[3], e;
+	int ref, empty;
+};
+struct WbrtBvh
+{
+	std::vector<WbrtBvhNode> nodes;
+	std::vector<int> tri_index; // leaf slot -> position in the grouped triangle order
+	std::vector<WbrtBvhRoot> roots;
+	int depth = 0;
+};
+void wbrt_build_bvh(const float4 *tri_geom, const int2 *ranges, int B, WbrtBvh &bvh);
 
 hipError_t wbrt_launch_render(const RenderParams &p, hipStream_t stream);
 hipError_t wbrt_launch_count(const RenderParams &p, hipStream_t stream);

@@ -5,7 +5,8 @@ portable-math mode and within MAE <= 1e-3 / PSNR >= 40 dB of the reference's gol
 import numpy as np
 import pytest
 
-from util import pkg, orc, golden, golden_meta, scene_by_tag, camera_by_meta, bits, image_error
+from util import (pkg, orc, golden, golden_meta, scene_by_tag, camera_by_meta, bits, image_error,
+                  scene_main_cpp_with_mesh, triangles_from_soup)
 
 pytestmark = pytest.mark.gpu
 
@@ -126,6 +127,69 @@ def test_against_oracle_bitwise(gpu_ctx, case):
     _, oc = O.render_frame(cam, seeds, counters=True)
     gc = gpu_ctx.count_events(cam)
     assert gc == dict(zip(pkg.COUNTER_NAMES, map(int, oc)))
+
+
+def _awkward_mesh_scene():
+    """Triangles chosen to trip a hierarchy walk: coincident duplicates with different
+    materials (the first in array order must win the tie), zero-area and NaN triangles, a few
+    very large ones among many small ones, two overlapping bounding boxes, triangles naming a
+    box that does not exist, and a box whose stated bounds do not contain its triangles."""
+    rs = np.random.RandomState(77)
+    n_small = 400
+    centers = rs.uniform([-1.2, -0.4, -2.2], [1.2, 0.9, -0.6], (n_small, 3))
+    small = centers[:, None, :] + rs.uniform(-0.12, 0.12, (n_small, 3, 3))
+    large = np.array([[[-3.0, -0.45, -3.0], [3.0, -0.45, -3.0], [0.0, -0.45, 1.0]],
+                      [[-2.0, -0.5, -2.5], [-2.0, 2.0, -2.5], [2.5, 0.5, -2.6]]])
+    dup = small[:40].copy()
+    flat = np.repeat(centers[40:46, None, :], 3, axis=1)               # zero area
+    nan = small[46:48].copy(); nan[0, 1, 2] = np.nan; nan[1, 0, 0] = np.inf
+    soup = np.concatenate([small, large, dup, flat, nan]).astype(np.float32).reshape(-1, 9)
+    n = soup.shape[0]
+    tris, mn, mx = triangles_from_soup(soup, (1, 1, 1), (0, 0, 0), pkg.material((0.7, 0.7, 0.7), 0.0, 0.0, pkg.LAMBERTIAN), 0)
+    arr = np.frombuffer(tris, dtype=np.float32).reshape(n, 16)
+    kinds = rs.randint(0, 4, n)
+    arr[:, 9:12] = rs.uniform(0.2, 1.0, (n, 3))
+    arr[:, 12] = np.where(rs.uniform(size=n) < 0.5, 0.0, 0.3)
+    arr[:, 13] = 1.5
+    arr.view(np.int32)[:, 14] = kinds
+    first_dup = n_small + 2
+    arr[first_dup:first_dup + 40, 9:12] = [1.0, 0.1, 0.1]             # duplicates: emissive red,
+    arr.view(np.int32)[first_dup:first_dup + 40, 14] = pkg.EMISSIVE   # never seen if the first wins
+    box_of = np.where(soup[:, 0] < 0.1, 0, 1).astype(np.int32)
+    box_of[rs.uniform(size=n) < 0.05] = 7                              # names no box: never tested
+    box_of[rs.uniform(size=n) < 0.05] = 2
+    arr.view(np.int32)[:, 15] = box_of
+    boxes = (pkg.BoundingBox * 3)()
+    boxes[0] = pkg.BoundingBox(0, pkg.vec3(-3.0, -0.6, -3.0), pkg.vec3(0.3, 2.0, 1.0))
+    boxes[1] = pkg.BoundingBox(1, pkg.vec3(-0.2, -0.6, -3.0), pkg.vec3(3.0, 2.0, 1.0))
+    boxes[2] = pkg.BoundingBox(2, pkg.vec3(-0.5, -0.2, -1.5), pkg.vec3(0.5, 0.5, -0.9))  # smaller than its contents
+    return pkg.Scene(spheres=pkg.scene_main_cpp().spheres, triangles=tris, boxes=boxes)
+
+
+@pytest.mark.parametrize("name", ["awkward", "f1_car", "stress"])
+def test_mesh_modes_identical(gpu_ctx, name):
+    """The hierarchy walks (strict and default margins) must reproduce the per-box triangle loop,
+    and the loop must reproduce the oracle."""
+    if name == "awkward":
+        scene, cam, check_oracle = _awkward_mesh_scene(), pkg.camera_main_cpp(192, 6, 50), True
+    elif name == "f1_car":
+        scene, cam, check_oracle = scene_main_cpp_with_mesh("f1_car"), pkg.camera_main_cpp(320, 6, 50), False
+    else:
+        scene, cam, check_oracle = pkg.scene_stress(60, 48, 48, 6, 6), pkg.camera_stress(256, 4, 50), False
+    seeds = _setup(gpu_ctx, scene, cam, 4, 21)
+    try:
+        images = {}
+        for mode in (pkg.MESH_LOOP, pkg.MESH_BVH_STRICT, pkg.MESH_BVH):
+            gpu_ctx.set_mesh_mode(mode)
+            images[mode] = gpu_ctx.render_frame(cam)
+    finally:
+        gpu_ctx.set_mesh_mode(pkg.MESH_BVH)
+    assert np.array_equal(bits(images[pkg.MESH_BVH_STRICT]), bits(images[pkg.MESH_LOOP]))
+    assert np.array_equal(bits(images[pkg.MESH_BVH]), bits(images[pkg.MESH_LOOP]))
+    if check_oracle:
+        O = orc.Oracle(scene)
+        assert np.array_equal(bits(images[pkg.MESH_LOOP]), bits(O.render_frame(cam, seeds)))
+        assert np.array_equal(gpu_ctx.primary_ids(cam), O.primary_ids(cam, seeds))
 
 
 def test_block_entry_point_equals_frame_region(gpu_ctx):
