@@ -128,6 +128,7 @@ int make_params(wbrt_context *ctx, const wbrt_camera *cam, bool whole_frame, Ren
 	p.sc = ctx->sc;
 	if (ctx->mesh_mode == WBRT_MESH_LOOP) p.sc.bvh_nodes = nullptr;
 	p.sc.bvh_rho = ctx->mesh_mode == WBRT_MESH_BVH ? ctx->bvh_rho : 0.0f;
+	p.sc.bvh_steal = std::getenv("WBRT_BVH_STEAL") ? std::atoi(std::getenv("WBRT_BVH_STEAL")) : 1;
 	return WBRT_OK;
 }
 

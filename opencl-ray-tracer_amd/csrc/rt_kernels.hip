@@ -661,6 +661,206 @@ __device__ __forceinline__ void triangles_bvh(const SceneDev &sc, int (*stack)[2
 	}
 }
 
+// Wave-cooperative walk of the same hierarchies.  Rays of a wave need very different amounts
+// of traversal (many miss every box, some cross the whole mesh), so a per-lane walk leaves
+// most lanes idle.  Here every lane of the wave is a WORKER with its own depth-first stack;
+// a worker without work takes (1) the next box its own ray hit, else (2) the OLDEST entry —
+// the largest unexplored subtree — from the stack of a worker that has spare entries.  A
+// worker that took foreign work loads that ray from LDS.  Hits are posted to the ray's slot in
+// LDS with a 64-bit atomic min on (t0 bits, loop position), which is the reference's
+// "first triangle wins ties" rule whatever the order of visits; the slot's t0 also prunes
+// subtrees for every worker on that ray.  A worker's stack only ever holds nodes of ONE ray and
+// one root-to-leaf path of siblings, so its depth is bounded by the tree depth.
+struct StealLds
+{
+	float ray[7][256];              // o.xyz d.xyz, sphere result (upper bound for accepted t0)
+	unsigned long long best[256];   // (t0 bits << 32) | loop position
+	int2 mail[256];                 // hand-over: node, ray slot | box << 8
+};
+
+struct BvhRay
+{
+	float4 o;
+	F3 d, inv;
+	float rc, dlen, padc, slop, e_limit, rho_pad;
+};
+
+__device__ __forceinline__ void bvh_load_ray(const StealLds &w, int slot, BvhRay &r)
+{
+	r.o = make_float4(w.ray[0][slot], w.ray[1][slot], w.ray[2][slot], 0.0f);
+	r.d = f3(w.ray[3][slot], w.ray[4][slot], w.ray[5][slot]);
+	r.rc = w.ray[6][slot];
+	r.inv = f3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+	r.dlen = sqrtf(dot(r.d, r.d)) * 1.000001f;
+}
+
+// margins of ray r against the hierarchy of `box`; returns its root reference (INT_MIN: no triangles)
+#define BVH_NONE ((int)0x80000000)
+__device__ __forceinline__ int bvh_enter_box(const SceneDev &sc, int box, BvhRay &r)
+{
+	const float4 r0 = sc.bvh_roots[2 * box], r1 = sc.bvh_roots[2 * box + 1];
+	const float far = fmaxf(fabsf(r.o.x - r0.x), fabsf(r.o.x - r1.x)) + fmaxf(fabsf(r.o.y - r0.y), fabsf(r.o.y - r1.y)) +
+	                  fmaxf(fabsf(r.o.z - r0.z), fabsf(r.o.z - r1.z));
+	const float diag = (r1.x - r0.x) + (r1.y - r0.y) + (r1.z - r0.z);
+	const float R = (far + diag) * 1.000001f;
+	r.padc = 0.35f * R * r.dlen;
+	r.slop = 1e-6f * (R + fabsf(r.o.x) + fabsf(r.o.y) + fabsf(r.o.z));
+	r.e_limit = 6.0f / r.dlen;
+	r.rho_pad = sc.bvh_rho * R + r.slop;
+	return r1.w < 0.0f ? BVH_NONE : __float_as_int(r0.w);
+}
+
+__device__ __forceinline__ void triangles_steal(const SceneDev &sc, int (*stack)[256], StealLds &w, bool trace,
+                                                F3 o, F3 d, float &closest, int &id)
+{
+	const float tmin = 0.001f;
+	const int col = threadIdx.x, base = threadIdx.x & ~63, lane = threadIdx.x & 63;
+	w.ray[0][col] = o.x; w.ray[1][col] = o.y; w.ray[2][col] = o.z;
+	w.ray[3][col] = d.x; w.ray[4][col] = d.y; w.ray[5][col] = d.z;
+	w.ray[6][col] = closest;
+	w.best[col] = ((unsigned long long)__float_as_uint(closest) << 32) | 0xFFFFFFFFull;
+	__builtin_amdgcn_wave_barrier();
+	BvhRay r;
+	bvh_load_ray(w, col, r);
+	const unsigned long long below = (1ull << lane) - 1ull;
+	for (int b0 = 0; b0 < sc.B; b0 += 64)
+	{
+		// boxes (of this group of 64) whose slab test passes for the lane's own ray
+		unsigned long long boxes = 0;
+		const int nb = sc.B - b0 < 64 ? sc.B - b0 : 64;
+		for (int b = 0; b < nb; ++b)
+		{
+			const float4 mn = sc.box_min[b0 + b], mx = sc.box_max[b0 + b];
+			float tx1 = (mn.x - o.x) * r.inv.x, tx2 = (mx.x - o.x) * r.inv.x;
+			float lo = fminf(tx1, tx2), hi = fmaxf(tx1, tx2);
+			float ty1 = (mn.y - o.y) * r.inv.y, ty2 = (mx.y - o.y) * r.inv.y;
+			lo = fmaxf(lo, fminf(ty1, ty2));
+			hi = fminf(hi, fmaxf(ty1, ty2));
+			float tz1 = (mn.z - o.z) * r.inv.z, tz2 = (mx.z - o.z) * r.inv.z;
+			lo = fmaxf(lo, fminf(tz1, tz2));
+			hi = fminf(hi, fmaxf(tz1, tz2));
+			if (trace && hi > fmaxf(lo, 0.0f)) boxes |= 1ull << b;
+		}
+		if (!__ballot(boxes != 0)) continue;
+
+		int node = BVH_NONE, sp = 0, bot = 0, cur = col, cur_box = 0;
+		for (;;)
+		{
+			if (node == BVH_NONE)
+			{
+				if (sp > bot)
+				{
+					node = stack[--sp][col];
+					if (sp == bot) sp = bot = 0;
+				}
+				else if (boxes)
+				{
+					cur_box = b0 + __builtin_ctzll(boxes);
+					boxes &= boxes - 1;
+					if (cur != col) { cur = col; bvh_load_ray(w, col, r); }
+					node = bvh_enter_box(sc, cur_box, r);
+				}
+			}
+			const unsigned long long idle = __ballot(node == BVH_NONE);
+			if (idle == ~0ull)
+			{
+				if (!__ballot(boxes != 0)) break;
+				continue; // a box without triangles was skipped; its lane tries its next box
+			}
+			if (idle)
+			{
+				const unsigned long long donors = __ballot(sp > bot);
+				if (donors)
+				{
+					const int nd = __popcll(donors), ni = __popcll(idle);
+					const int m = nd < ni ? nd : ni;
+					if (((donors >> lane) & 1ull) != 0)
+					{
+						const int k = __popcll(donors & below);
+						if (k < m)
+						{
+							w.mail[base + k] = make_int2(stack[bot][col], (cur - base) | (cur_box << 8));
+							++bot;
+							if (sp == bot) sp = bot = 0;
+						}
+					}
+					__builtin_amdgcn_wave_barrier();
+					if (((idle >> lane) & 1ull) != 0)
+					{
+						const int k = __popcll(idle & below);
+						if (k < m)
+						{
+							const int2 got = w.mail[base + k];
+							node = got.x;
+							cur = base + (got.y & 255);
+							cur_box = got.y >> 8;
+							bvh_load_ray(w, cur, r);
+							(void)bvh_enter_box(sc, cur_box, r);
+						}
+					}
+					__builtin_amdgcn_wave_barrier();
+				}
+			}
+			if (node == BVH_NONE) continue;
+			if (node >= 0)
+			{
+				const float4 q0 = sc.bvh_nodes[4 * (size_t)node], q1 = sc.bvh_nodes[4 * (size_t)node + 1];
+				const float4 q2 = sc.bvh_nodes[4 * (size_t)node + 2], q3 = sc.bvh_nodes[4 * (size_t)node + 3];
+				const float best = __uint_as_float((unsigned)(w.best[cur] >> 32));
+				float pad_l = q3.z <= r.e_limit ? q3.z * r.padc + r.slop : INFINITY;
+				float pad_r = q3.w <= r.e_limit ? q3.w * r.padc + r.slop : INFINITY;
+				if (sc.bvh_rho > 0.0f)
+				{
+					pad_l = fminf(pad_l, r.rho_pad);
+					pad_r = fminf(pad_r, r.rho_pad);
+				}
+				float lo_l, lo_r;
+				const bool vl = bvh_box(r.o, r.inv, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, pad_l, best, lo_l);
+				const bool vr = bvh_box(r.o, r.inv, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, pad_r, best, lo_r);
+				const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
+				const bool left_first = !(lo_r < lo_l);
+				if (vl & vr) stack[sp++][col] = left_first ? right : left;
+				node = (vl & vr) ? (left_first ? left : right) : vl ? left : vr ? right : BVH_NONE;
+			}
+			else
+			{
+				// one triangle of the leaf per round
+				const int leaf = ~node;
+				const int first = leaf >> 4, more = leaf & 15;
+				node = more ? ~(((first + 1) << 4) | (more - 1)) : BVH_NONE;
+				const float4 g0 = sc.bvh_tris[3 * (size_t)first];
+				const float4 g1 = sc.bvh_tris[3 * (size_t)first + 1];
+				const float4 g2 = sc.bvh_tris[3 * (size_t)first + 2];
+				const F3 p0 = f3(g0.x, g0.y, g0.z), e0 = f3(g0.w, g1.x, g1.y), e1 = f3(g1.z, g1.w, g2.x);
+				const F3 ro = f3(r.o.x, r.o.y, r.o.z);
+				F3 h = cross(r.d, e1);
+				float det = dot(e0, h);
+				if (det > -0.00001f && det < 0.00001f) continue;
+				float f = 1.0f / det;
+				F3 sv = ro - p0;
+				float u = f * dot(sv, h);
+				if (u < 0.0f || u > 1.0f) continue;
+				F3 q = cross(sv, e0);
+				float v = f * dot(r.d, q);
+				if (v < 0.0f || u + v > 1.0f) continue;
+				float t0 = f * dot(e1, q);
+				if (t0 > tmin && t0 < r.rc)
+					atomicMin(&w.best[cur], ((unsigned long long)__float_as_uint(t0) << 32) | (unsigned)__float_as_int(g2.y));
+			}
+		}
+		// the next group of boxes starts from the own ray again
+		if (cur != col) { cur = col; bvh_load_ray(w, col, r); }
+		__builtin_amdgcn_wave_barrier();
+	}
+	__builtin_amdgcn_wave_barrier();
+	const unsigned long long k = w.best[col];
+	if (trace && (unsigned)k != 0xFFFFFFFFu)
+	{
+		closest = __uint_as_float((unsigned)(k >> 32));
+		id = sc.S + (int)(unsigned)k;
+	}
+}
+
 // The counting build always takes the exact sphere loop: its counters are defined by the
 // reference's sequential order of decisions.
 template <bool STATS>
@@ -782,6 +982,7 @@ __global__ __launch_bounds__(256) void k_render(const RenderParams p)
 	__shared__ TriTiles s_tiles[MESH && STATS ? 4 : 1]; // counting build: sequential staged loop, one per wave
 	__shared__ unsigned long long s_best[MESH && !STATS ? 4 : 1][64];
 	__shared__ int s_stack[MESH && !STATS ? WBRT_BVH_STACK : 1][256]; // one column per thread
+	__shared__ StealLds s_steal[MESH && !STATS ? 1 : 1];
 	Counters<STATS> ctr;
 	const SceneDev &sc = p.sc;
 	long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -841,6 +1042,7 @@ __global__ __launch_bounds__(256) void k_render(const RenderParams p)
 			{
 				if (trace) boxes_and_triangles<STATS>(sc, s_tiles[threadIdx.x >> 6], L.o, L.d, t, id, ctr);
 			}
+			else if (sc.bvh_nodes && sc.bvh_steal) triangles_steal(sc, s_stack, s_steal[0], trace, L.o, L.d, t, id);
 			else if (sc.bvh_nodes)
 			{
 				if (trace) triangles_bvh(sc, s_stack, L.o, L.d, t, id);

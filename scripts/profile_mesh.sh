@@ -2,13 +2,16 @@
 # Profiles the mesh scene (main.cpp spheres + f1_car, 1920x1080, 4 spp) : stats + SQ + memory counters.
 set -u
 TAG=${1:-mesh}
+SPP=${2:-4}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-B="python3 scripts/c3_quick.py 1920 4"
+B="python3 scripts/c3_quick.py 1920 $SPP"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $B > $OUT/stats.log 2>&1 || { echo "stats failed"; tail -5 $OUT/stats.log; exit 1; }
 timeout -s KILL 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/pmc_sq -- $B > $OUT/pmc_sq.log 2>&1 || { echo "pmc sq failed"; tail -5 $OUT/pmc_sq.log; exit 1; }
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE TCC_HIT_sum --output-format csv -d $OUT/pmc_fetch -- $B > $OUT/pmc_fetch.log 2>&1 || { echo "pmc fetch failed"; tail -5 $OUT/pmc_fetch.log; }
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE TCC_MISS_sum TCC_REQ_sum --output-format csv -d $OUT/pmc_write -- $B > $OUT/pmc_write.log 2>&1 || { echo "pmc write failed"; tail -5 $OUT/pmc_write.log; }
+timeout -s KILL 300 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM --output-format csv -d $OUT/pmc_sq2 -- $B > $OUT/pmc_sq2.log 2>&1 || { echo "pmc sq2 failed"; tail -5 $OUT/pmc_sq2.log; }
+timeout -s KILL 300 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum --output-format csv -d $OUT/pmc_tcp -- $B > $OUT/pmc_tcp.log 2>&1 || { echo "pmc tcp failed"; tail -5 $OUT/pmc_tcp.log; }
 python3 scripts/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt

@@ -20,7 +20,7 @@ def pmc(dirname):
             acc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
     return acc
 
-for d in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
+for d in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write", "pmc_tcp"):
     acc = pmc(d)
     if not acc:
         continue
