@@ -52,8 +52,16 @@ struct Builder
 {
 	std::vector<Prim> prims;
 	WbrtBvh *out;
-	bool median_only;
+	int depth_limit;
 	int max_depth = 0;
+
+	// inner levels a balanced (object-median) subtree over `count` triangles needs
+	static int balanced_levels(int count)
+	{
+		int leaves = (count + kLeaf - 1) / kLeaf, levels = 0;
+		while ((1 << levels) < leaves) ++levels;
+		return levels;
+	}
 
 	static constexpr int kLeaf = 4, kBins = 16;
 
@@ -84,7 +92,7 @@ struct Builder
 		for (int a = 1; a < 3; ++a) if (cb.mx[a] - cb.mn[a] > cb.mx[axis] - cb.mn[axis]) axis = a;
 		int mid = -1;
 		const double extent = cb.mx[axis] - cb.mn[axis];
-		if (!median_only && extent > 0.0 && std::isfinite(extent))
+		if (extent > 0.0 && std::isfinite(extent))
 		{
 			// binned surface-area heuristic on the widest centroid axis
 			Bounds bin_b[kBins];
@@ -122,11 +130,15 @@ struct Builder
 				                         [&](const Prim &p) { return bin_of(p) <= best_k; });
 				mid = (int)(it - prims.begin());
 				if (mid == first || mid == first + count) mid = -1;
+				// a lopsided split is taken only if the larger side can still be finished, balanced
+				// if need be, within the depth the kernel's stack allows
+				else if (depth + 1 + balanced_levels(std::max(mid - first, first + count - mid)) > depth_limit) mid = -1;
 			}
 		}
 		if (mid < 0)
 		{
-			// object median; ties broken by index so that the split always has two sides
+			// object median (also the fallback that bounds the depth); ties broken by index so that
+			// the split always has two sides
 			mid = first + count / 2;
 			std::nth_element(prims.begin() + first, prims.begin() + mid, prims.begin() + first + count,
 			                 [&](const Prim &a, const Prim &b) {
@@ -190,27 +202,41 @@ void wbrt_build_bvh(const float4 *tri_geom, const int2 *ranges, int B, WbrtBvh &
 			if (!std::isfinite(p.e)) p.e = DBL_MAX;
 			p.index = first + i;
 		}
-		for (int attempt = 0; attempt < 2; ++attempt)
-		{
-			const size_t nodes_before = bvh.nodes.size(), tris_before = bvh.tri_index.size();
-			Builder bl;
-			bl.prims = prims;
-			bl.out = &bvh;
-			bl.median_only = attempt == 1;
-			Bounds rb;
-			double re;
-			root.ref = bl.build(0, count, 0, rb, re);
-			if (bl.max_depth < WBRT_BVH_STACK || attempt == 1)
-			{
-				for (int a = 0; a < 3; ++a) { root.mn[a] = round_down(rb.mn[a]); root.mx[a] = round_up(rb.mx[a]); }
-				root.e = round_up(re * 1.000001);
-				root.empty = 0;
-				bvh.depth = std::max(bvh.depth, bl.max_depth);
-				break;
-			}
-			// a surface-area tree deeper than the kernel's stack: rebuild balanced
-			bvh.nodes.resize(nodes_before);
-			bvh.tri_index.resize(tris_before);
-		}
+		Builder bl;
+		bl.prims = std::move(prims);
+		bl.out = &bvh;
+		bl.depth_limit = WBRT_BVH_STACK;
+		Bounds rb;
+		double re;
+		root.ref = bl.build(0, count, 0, rb, re);
+		for (int a = 0; a < 3; ++a) { root.mn[a] = round_down(rb.mn[a]); root.mx[a] = round_up(rb.mx[a]); }
+		root.e = round_up(re * 1.000001);
+		root.empty = 0;
+		bvh.depth = std::max(bvh.depth, bl.max_depth);
 	}
+}
+
+// Test hook (not in the public header): runs the builder on host arrays and copies the result
+// out.  tri_geom: 12 floats per triangle in the device layout; ranges: first,last per box;
+// nodes_out: 16 floats per node; roots_out: 8 floats per box (min.xyz ref | max.xyz E, E < 0 =
+// empty).  Returns the node count, or -(needed nodes) - 1 when nodes_cap is too small.
+extern "C" int wbrt_bvh_build_(const float *tri_geom, const int *ranges, int B, float *nodes_out, int nodes_cap,
+                               int *tri_index_out, int tri_cap, float *roots_out, int *depth_out)
+{
+	WbrtBvh bvh;
+	wbrt_build_bvh(reinterpret_cast<const float4 *>(tri_geom), reinterpret_cast<const int2 *>(ranges), B, bvh);
+	if ((int)bvh.nodes.size() > nodes_cap || (int)bvh.tri_index.size() > tri_cap) return -(int)bvh.nodes.size() - 1;
+	if (!bvh.nodes.empty()) std::memcpy(nodes_out, bvh.nodes.data(), bvh.nodes.size() * sizeof(WbrtBvhNode));
+	if (!bvh.tri_index.empty()) std::memcpy(tri_index_out, bvh.tri_index.data(), bvh.tri_index.size() * sizeof(int));
+	for (int b = 0; b < B; ++b)
+	{
+		const WbrtBvhRoot &r = bvh.roots[(size_t)b];
+		float *o = roots_out + 8 * (size_t)b;
+		o[0] = r.mn[0]; o[1] = r.mn[1]; o[2] = r.mn[2];
+		std::memcpy(&o[3], &r.ref, 4);
+		o[4] = r.mx[0]; o[5] = r.mx[1]; o[6] = r.mx[2];
+		o[7] = r.empty ? -1.0f : r.e;
+	}
+	if (depth_out) *depth_out = bvh.depth;
+	return (int)bvh.nodes.size();
 }

@@ -76,7 +76,7 @@ struct RenderParams
 
 // Binary hierarchy over the triangles of every bounding box.  A child reference >= 0 names a
 // node; < 0 names a leaf: ~ref = (first leaf slot << 4) | (triangles - 1).
-#define WBRT_BVH_STACK 32
+#define WBRT_BVH_STACK 24
 struct WbrtBvhNode
 {
 	float lmin[3], lmax[3], rmin[3], rmax[3];

@@ -767,7 +767,7 @@ __device__ __forceinline__ void triangles_steal(const SceneDev &sc, int (*stack)
 				if (!__ballot(boxes != 0)) break;
 				continue; // a box without triangles was skipped; its lane tries its next box
 			}
-			if (idle)
+			if (__popcll(idle) >= ((sc.bvh_steal >> 8) & 255))
 			{
 				const unsigned long long donors = __ballot(sp > bot);
 				if (donors)
@@ -779,8 +779,8 @@ __device__ __forceinline__ void triangles_steal(const SceneDev &sc, int (*stack)
 						const int k = __popcll(donors & below);
 						if (k < m)
 						{
-							w.mail[base + k] = make_int2(stack[bot][col], (cur - base) | (cur_box << 8));
-							++bot;
+							if (sc.bvh_steal & 2) { w.mail[base + k] = make_int2(stack[sp - 1][col], (cur - base) | (cur_box << 8)); --sp; }
+							else { w.mail[base + k] = make_int2(stack[bot][col], (cur - base) | (cur_box << 8)); ++bot; }
 							if (sp == bot) sp = bot = 0;
 						}
 					}
