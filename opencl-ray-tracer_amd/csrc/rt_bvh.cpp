@@ -53,6 +53,7 @@ struct Builder
 	std::vector<Prim> prims;
 	WbrtBvh *out;
 	int depth_limit;
+	bool split_by_e;
 	int max_depth = 0;
 
 	// inner levels a balanced (object-median) subtree over `count` triangles needs
@@ -91,8 +92,23 @@ struct Builder
 		int axis = 0;
 		for (int a = 1; a < 3; ++a) if (cb.mx[a] - cb.mn[a] > cb.mx[axis] - cb.mn[axis]) axis = a;
 		int mid = -1;
+		// A node's box margin grows with the largest |e0||e1| below it, so a few large triangles
+		// would widen every box above them.  When they are a small minority they get a subtree of
+		// their own, whatever their position.
+		if (split_by_e && count > 4 * kLeaf && emax > 0.0 && std::isfinite(emax))
+		{
+			const double cut = emax / 8.0;
+			int big = 0;
+			for (int i = first; i < first + count; ++i) big += prims[(size_t)i].e > cut;
+			if (big > 0 && big * 8 <= count && depth + 1 + balanced_levels(count - big) <= depth_limit)
+			{
+				auto it = std::partition(prims.begin() + first, prims.begin() + first + count,
+				                         [&](const Prim &p) { return !(p.e > cut); });
+				mid = (int)(it - prims.begin());
+			}
+		}
 		const double extent = cb.mx[axis] - cb.mn[axis];
-		if (extent > 0.0 && std::isfinite(extent))
+		if (mid < 0 && extent > 0.0 && std::isfinite(extent))
 		{
 			// binned surface-area heuristic on the widest centroid axis
 			Bounds bin_b[kBins];
@@ -169,8 +185,9 @@ struct Builder
 
 // tri_geom: the grouped triangle array of the device scene (3 float4 per triangle: p0.xyz e0.x |
 // e0.yz e1.xy | e1.z - - -); ranges[b] = [first, last) of box b.  Node and leaf indices are
-// global over all boxes.
-void wbrt_build_bvh(const float4 *tri_geom, const int2 *ranges, int B, WbrtBvh &bvh)
+// global over all boxes.  split_by_e: give minorities of large triangles subtrees of their own
+// (tighter strict margins, looser boxes).
+void wbrt_build_bvh(const float4 *tri_geom, const int2 *ranges, int B, bool split_by_e, WbrtBvh &bvh)
 {
 	bvh.nodes.clear();
 	bvh.tri_index.clear();
@@ -206,6 +223,7 @@ void wbrt_build_bvh(const float4 *tri_geom, const int2 *ranges, int B, WbrtBvh &
 		bl.prims = std::move(prims);
 		bl.out = &bvh;
 		bl.depth_limit = WBRT_BVH_STACK;
+		bl.split_by_e = split_by_e;
 		Bounds rb;
 		double re;
 		root.ref = bl.build(0, count, 0, rb, re);
@@ -221,10 +239,10 @@ void wbrt_build_bvh(const float4 *tri_geom, const int2 *ranges, int B, WbrtBvh &
 // nodes_out: 16 floats per node; roots_out: 8 floats per box (min.xyz ref | max.xyz E, E < 0 =
 // empty).  Returns the node count, or -(needed nodes) - 1 when nodes_cap is too small.
 extern "C" int wbrt_bvh_build_(const float *tri_geom, const int *ranges, int B, float *nodes_out, int nodes_cap,
-                               int *tri_index_out, int tri_cap, float *roots_out, int *depth_out)
+                               int *tri_index_out, int tri_cap, float *roots_out, int *depth_out, int split_by_e)
 {
 	WbrtBvh bvh;
-	wbrt_build_bvh(reinterpret_cast<const float4 *>(tri_geom), reinterpret_cast<const int2 *>(ranges), B, bvh);
+	wbrt_build_bvh(reinterpret_cast<const float4 *>(tri_geom), reinterpret_cast<const int2 *>(ranges), B, split_by_e != 0, bvh);
 	if ((int)bvh.nodes.size() > nodes_cap || (int)bvh.tri_index.size() > tri_cap) return -(int)bvh.nodes.size() - 1;
 	if (!bvh.nodes.empty()) std::memcpy(nodes_out, bvh.nodes.data(), bvh.nodes.size() * sizeof(WbrtBvhNode));
 	if (!bvh.tri_index.empty()) std::memcpy(tri_index_out, bvh.tri_index.data(), bvh.tri_index.size() * sizeof(int));

@@ -64,7 +64,9 @@ struct wbrt_context
 	hipStream_t stream = nullptr; // used by the blocking entry points
 	DevBuf sph_geom, sph_radius, sph_mat_a, sph_mat_b;
 	DevBuf tri_geom, tri_mat_a, tri_mat_b, tri_orig;
-	DevBuf box_min, box_max, box_range, bvh_nodes, bvh_tris, bvh_roots;
+	DevBuf box_min, box_max, box_range;
+	DevBuf bvh_nodes[2], bvh_tris[2], bvh_roots[2]; // [0] plain surface-area trees, [1] built for the strict margins
+	const float4 *bvh_ptr[2][3] = {};
 	int mesh_mode = WBRT_MESH_BVH;
 	int bvh_steal = 1 | (8 << 8);
 	float bvh_rho = 1e-4f; // WBRT_MESH_BVH: box margin as a fraction of the ray's distance bound
@@ -72,7 +74,7 @@ struct wbrt_context
 	int lpt = 1;        // longest-first scheduling from a pilot pass
 	int pilot_spp = 4;
 	SceneDev sc{};
-	bool have_scene = false, have_sky = false;
+	bool have_scene = false, have_sky = false, have_bvh = false;
 	size_t n_seeds = 0;
 	bool timing = false;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -127,7 +129,13 @@ int make_params(wbrt_context *ctx, const wbrt_camera *cam, bool whole_frame, Ren
 	}
 	p.seeds = (const uint32_t *)ctx->seeds.p;
 	p.sc = ctx->sc;
-	if (ctx->mesh_mode == WBRT_MESH_LOOP) p.sc.bvh_nodes = nullptr;
+	if (ctx->mesh_mode != WBRT_MESH_LOOP && ctx->have_bvh)
+	{
+		const int variant = ctx->mesh_mode == WBRT_MESH_BVH_STRICT ? 1 : 0;
+		p.sc.bvh_nodes = ctx->bvh_ptr[variant][0];
+		p.sc.bvh_tris = ctx->bvh_ptr[variant][1];
+		p.sc.bvh_roots = ctx->bvh_ptr[variant][2];
+	}
 	p.sc.bvh_rho = ctx->mesh_mode == WBRT_MESH_BVH ? ctx->bvh_rho : 0.0f;
 	// bit 0: wave-cooperative walk with work stealing (0: every lane walks alone); bit 1: steal the newest
 	// instead of the oldest entry; bits 8-15: idle lanes needed before a steal round is run
@@ -212,7 +220,8 @@ int wbrt_destroy(wbrt_context *ctx)
 	for (auto &ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
 	DevBuf *all[] = { &ctx->sph_geom, &ctx->sph_radius, &ctx->sph_mat_a, &ctx->sph_mat_b, &ctx->tri_geom,
 	                  &ctx->tri_mat_a, &ctx->tri_mat_b, &ctx->tri_orig, &ctx->box_min, &ctx->box_max,
-	                  &ctx->box_range, &ctx->bvh_nodes, &ctx->bvh_tris, &ctx->bvh_roots, &ctx->sky, &ctx->seeds, &ctx->image, &ctx->ids, &ctx->counters, &ctx->rgb8,
+	                  &ctx->box_range, &ctx->bvh_nodes[0], &ctx->bvh_tris[0], &ctx->bvh_roots[0],
+	                  &ctx->bvh_nodes[1], &ctx->bvh_tris[1], &ctx->bvh_roots[1], &ctx->sky, &ctx->seeds, &ctx->image, &ctx->ids, &ctx->counters, &ctx->rgb8,
 	                  &ctx->costs, &ctx->tile_costs, &ctx->order, &ctx->hist };
 	for (DevBuf *b : all) b->release();
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -287,15 +296,13 @@ int wbrt_upload_scene(wbrt_context *ctx, const wbrt_sphere *spheres, int32_t S,
 	UP(tri_geom, tgeom); UP(tri_mat_a, tmat_a); UP(tri_mat_b, tmat_b); UP(tri_orig, torig);
 	UP(box_min, bmin); UP(box_max, bmax); UP(box_range, brange);
 	// triangle hierarchies (render build only; the counting and primary-id builds keep the loop)
-	WbrtBvh bvh;
-	std::vector<float4> bnodes, btris, broots;
-	if (Tg > 0)
+	for (int variant = 0; variant < 2 && Tg > 0; ++variant)
 	{
-		wbrt_build_bvh(tgeom.data(), brange.data(), B, bvh);
+		WbrtBvh bvh;
+		wbrt_build_bvh(tgeom.data(), brange.data(), B, variant == 1, bvh);
 		static_assert(sizeof(WbrtBvhNode) == 4 * sizeof(float4), "node layout");
-		bnodes.resize(bvh.nodes.size() * 4);
+		std::vector<float4> bnodes(bvh.nodes.size() * 4), btris(bvh.tri_index.size() * 3), broots((size_t)B * 2);
 		if (!bvh.nodes.empty()) std::memcpy(bnodes.data(), bvh.nodes.data(), bvh.nodes.size() * sizeof(WbrtBvhNode));
-		btris.resize(bvh.tri_index.size() * 3);
 		for (size_t k = 0; k < bvh.tri_index.size(); ++k)
 		{
 			const size_t src = (size_t)bvh.tri_index[k];
@@ -306,7 +313,6 @@ int wbrt_upload_scene(wbrt_context *ctx, const wbrt_sphere *spheres, int32_t S,
 			std::memcpy(&last.y, &pos, 4);
 			btris[3 * k + 2] = last;
 		}
-		broots.resize((size_t)B * 2);
 		for (int b = 0; b < B; ++b)
 		{
 			const WbrtBvhRoot &r = bvh.roots[(size_t)b];
@@ -314,14 +320,15 @@ int wbrt_upload_scene(wbrt_context *ctx, const wbrt_sphere *spheres, int32_t S,
 			broots[2 * (size_t)b] = make_float4(r.mn[0], r.mn[1], r.mn[2], ref);
 			broots[2 * (size_t)b + 1] = make_float4(r.mx[0], r.mx[1], r.mx[2], r.empty ? -1.0f : r.e);
 		}
-		UP(bvh_nodes, bnodes); UP(bvh_tris, btris); UP(bvh_roots, broots);
+		UP(bvh_nodes[variant], bnodes); UP(bvh_tris[variant], btris); UP(bvh_roots[variant], broots);
+		ctx->bvh_ptr[variant][0] = (const float4 *)ctx->bvh_nodes[variant].p;
+		ctx->bvh_ptr[variant][1] = (const float4 *)ctx->bvh_tris[variant].p;
+		ctx->bvh_ptr[variant][2] = (const float4 *)ctx->bvh_roots[variant].p;
 	}
+	ctx->have_bvh = Tg > 0;
 #undef UP
 	SceneDev &sc = ctx->sc;
-	const bool have_bvh = Tg > 0;
-	sc.bvh_nodes = have_bvh ? (const float4 *)ctx->bvh_nodes.p : nullptr;
-	sc.bvh_tris = have_bvh ? (const float4 *)ctx->bvh_tris.p : nullptr;
-	sc.bvh_roots = have_bvh ? (const float4 *)ctx->bvh_roots.p : nullptr;
+	sc.bvh_nodes = sc.bvh_tris = sc.bvh_roots = nullptr; // chosen per render (make_params)
 	sc.bvh_rho = 0.0f;
 	sc.sph_geom = (const float4 *)ctx->sph_geom.p; sc.sph_radius = (const float *)ctx->sph_radius.p;
 	sc.sph_mat_a = (const float4 *)ctx->sph_mat_a.p; sc.sph_mat_b = (const float2 *)ctx->sph_mat_b.p;

@@ -95,7 +95,7 @@ struct WbrtBvh
 	std::vector<WbrtBvhRoot> roots;
 	int depth = 0;
 };
-void wbrt_build_bvh(const float4 *tri_geom, const int2 *ranges, int B, WbrtBvh &bvh);
+void wbrt_build_bvh(const float4 *tri_geom, const int2 *ranges, int B, bool split_by_e, WbrtBvh &bvh);
 
 hipError_t wbrt_launch_render(const RenderParams &p, hipStream_t stream);
 hipError_t wbrt_launch_count(const RenderParams &p, hipStream_t stream);

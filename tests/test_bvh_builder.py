@@ -11,7 +11,7 @@ from util import pkg, golden, triangles_from_soup
 STACK = 24  # WBRT_BVH_STACK in csrc/rt_device.h
 
 
-def _build(geom, ranges):
+def _build(geom, ranges, split_by_e=0):
     L = pkg.lib()
     L.wbrt_bvh_build_.restype = C.c_int
     T, B = geom.shape[0], ranges.shape[0]
@@ -20,7 +20,7 @@ def _build(geom, ranges):
     roots = np.zeros((B, 8), np.float32)
     depth = C.c_int(0)
     p = lambda a: a.ctypes.data_as(C.c_void_p)
-    n = L.wbrt_bvh_build_(p(geom), p(ranges), B, p(nodes), nodes.shape[0], p(tri_index), tri_index.shape[0], p(roots), C.byref(depth))
+    n = L.wbrt_bvh_build_(p(geom), p(ranges), B, p(nodes), nodes.shape[0], p(tri_index), tri_index.shape[0], p(roots), C.byref(depth), split_by_e)
     assert n >= 0
     return nodes[:n], tri_index, roots, depth.value
 
@@ -95,8 +95,9 @@ def test_builder_invariants(mesh):
         ranges = np.array([[0, 1000], [1000, 1000], [1000, T]], np.int32)  # one empty box
     else:
         ranges = np.array([[0, T]], np.int32)
-    nodes, tri_index, roots, depth = _build(geom, ranges)
-    _check_tree(geom, ranges, nodes, tri_index, roots, depth)
+    for split_by_e in (0, 1):
+        nodes, tri_index, roots, depth = _build(geom, ranges, split_by_e)
+        _check_tree(geom, ranges, nodes, tri_index, roots, depth)
 
 
 def test_builder_handles_non_finite_vertices():
