@@ -82,9 +82,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+    # Rehearsal on a box with fewer GPUs than ranks (never used for a reported number):
+    # WBRT_BENCH_SHARE_GPU=1 maps ranks onto the GPUs present, WBRT_BENCH_BACKEND=gloo replaces RCCL,
+    # which refuses two ranks on one device.
+    backend = os.environ.get("WBRT_BENCH_BACKEND", "nccl")
+    if os.environ.get("WBRT_BENCH_SHARE_GPU") == "1":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     pkg = entry.load_package()
     mg = __import__("importlib").import_module(entry.PKG_NAME + ".multi_gpu")
@@ -111,9 +120,18 @@ def main():
     frame = mg.FrameBuffers(cam.width, cam.height, torch.device("cuda", local_rank))
     stream = torch.cuda.current_stream().cuda_stream
 
+    def all_reduce(t, op=None):
+        op = op or dist.ReduceOp.SUM
+        if backend == "nccl":
+            dist.all_reduce(t, op=op)
+        else:  # rehearsal backend: stage through the host
+            h = t.cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
+
     def step():
         mg.render_step(ctx, cam, frame, total_spp=spp * world, stream=stream,
-                       all_reduce=(lambda t: dist.all_reduce(t)) if world > 1 else None)
+                       all_reduce=all_reduce if world > 1 else None)
 
     def barrier():
         torch.cuda.synchronize()
@@ -134,7 +152,7 @@ def main():
     ctx.set_timing(False)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce(t, dist.ReduceOp.MAX)
         dt = float(t.item())
 
     paths_per_step = cam.width * cam.height * spp * world
