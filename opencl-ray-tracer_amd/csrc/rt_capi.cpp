@@ -68,7 +68,7 @@ struct wbrt_context
 	DevBuf bvh_nodes[2], bvh_tris[2], bvh_roots[2]; // [0] plain surface-area trees, [1] built for the strict margins
 	const float4 *bvh_ptr[2][3] = {};
 	int mesh_mode = WBRT_MESH_BVH;
-	int bvh_steal = 1 | (8 << 8);
+	int bvh_steal_min_idle = 8;
 	float bvh_rho = 1e-4f; // WBRT_MESH_BVH: box margin as a fraction of the ray's distance bound
 	DevBuf sky, seeds, image, ids, counters, rgb8, costs, tile_costs, order, hist;
 	int lpt = 1;        // longest-first scheduling from a pilot pass
@@ -137,9 +137,7 @@ int make_params(wbrt_context *ctx, const wbrt_camera *cam, bool whole_frame, Ren
 		p.sc.bvh_roots = ctx->bvh_ptr[variant][2];
 	}
 	p.sc.bvh_rho = ctx->mesh_mode == WBRT_MESH_BVH ? ctx->bvh_rho : 0.0f;
-	// bit 0: wave-cooperative walk with work stealing (0: every lane walks alone); bit 1: steal the newest
-	// instead of the oldest entry; bits 8-15: idle lanes needed before a steal round is run
-	p.sc.bvh_steal = ctx->bvh_steal;
+	p.sc.bvh_steal_min_idle = ctx->bvh_steal_min_idle;
 	return WBRT_OK;
 }
 
@@ -205,7 +203,7 @@ int wbrt_create(int device_ordinal, wbrt_context **out)
 	// tuning knobs for experiments (not part of the ABI contract)
 	if (const char *v = std::getenv("WBRT_LPT")) ctx->lpt = std::atoi(v) != 0;
 	if (const char *v = std::getenv("WBRT_MESH_MODE")) { int m = std::atoi(v); if (m >= 0 && m <= 2) ctx->mesh_mode = m; }
-	if (const char *v = std::getenv("WBRT_BVH_STEAL")) ctx->bvh_steal = std::atoi(v);
+	if (const char *v = std::getenv("WBRT_BVH_MIN_IDLE")) ctx->bvh_steal_min_idle = std::atoi(v);
 	if (const char *v = std::getenv("WBRT_BVH_RHO")) { float r = (float)std::atof(v); if (r > 0.0f) ctx->bvh_rho = r; }
 	if (const char *v = std::getenv("WBRT_PILOT_SPP")) ctx->pilot_spp = std::atoi(v) > 0 ? std::atoi(v) : 4;
 	*out = ctx;

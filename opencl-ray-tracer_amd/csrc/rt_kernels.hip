@@ -534,8 +534,7 @@ __device__ __forceinline__ void triangles_cooperative(const SceneDev &sc, unsign
 	}
 }
 
-// Per-lane walk of the triangle hierarchies (built on upload, see rt_bvh.cpp) for the render
-// build.  A box of the scene is entered only when the reference's own slab test passes
+// Walk of the triangle hierarchies (built on upload, see rt_bvh.cpp) for the render build.  A box of the scene is entered only when the reference's own slab test passes
 // (gpu_kernel.cl:534-555), exactly like its triangle loop; inside, the triangle test is the
 // reference's, and the winner is the lexicographic minimum of (t0, loop position) among
 // accepted hits below the sphere result — what the sequential loop with its strict
@@ -555,113 +554,7 @@ __device__ __forceinline__ bool bvh_box(float4 ray_o, F3 inv, float mnx, float m
 	return !(lo > hi) & !(hi < 0.0f) & !(lo > best);
 }
 
-__device__ __forceinline__ void triangles_bvh(const SceneDev &sc, int (*stack)[256], F3 o, F3 d, float &closest, int &id)
-{
-	const float tmin = 0.001f;
-	const int tid = threadIdx.x;
-	const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
-	const F3 inv = f3(ix, iy, iz);
-	const float4 ro = make_float4(o.x, o.y, o.z, 0.0f);
-	const float dlen = sqrtf(dot(d, d)) * 1.000001f;
-	float best = closest;
-	int best_pos = -1;
-	for (int b = 0; b < sc.B; ++b)
-	{
-		const float4 mn = sc.box_min[b], mx = sc.box_max[b];
-		float tx1 = (mn.x - o.x) * ix, tx2 = (mx.x - o.x) * ix;
-		float lo = fminf(tx1, tx2), hi = fmaxf(tx1, tx2);
-		float ty1 = (mn.y - o.y) * iy, ty2 = (mx.y - o.y) * iy;
-		lo = fmaxf(lo, fminf(ty1, ty2));
-		hi = fminf(hi, fmaxf(ty1, ty2));
-		float tz1 = (mn.z - o.z) * iz, tz2 = (mx.z - o.z) * iz;
-		lo = fmaxf(lo, fminf(tz1, tz2));
-		hi = fminf(hi, fmaxf(tz1, tz2));
-		if (!(hi > fmaxf(lo, 0.0f))) continue;
-		const float4 r0 = sc.bvh_roots[2 * b], r1 = sc.bvh_roots[2 * b + 1];
-		if (r1.w < 0.0f) continue; // no triangles
-		// R >= |o - p0| + |e| for every triangle below: 1-norm of the vector to the far corner
-		// of the hierarchy's bounds plus the 1-norm of their diagonal
-		const float far = fmaxf(fabsf(o.x - r0.x), fabsf(o.x - r1.x)) + fmaxf(fabsf(o.y - r0.y), fabsf(o.y - r1.y)) +
-		                  fmaxf(fabsf(o.z - r0.z), fabsf(o.z - r1.z));
-		const float diag = (r1.x - r0.x) + (r1.y - r0.y) + (r1.z - r0.z);
-		const float R = (far + diag) * 1.000001f;
-		const float padc = 0.35f * R * dlen;
-		// rounding of the box arithmetic itself: a few ulp of the coordinates and distances involved
-		const float slop = 1e-6f * (R + fabsf(o.x) + fabsf(o.y) + fabsf(o.z));
-		// above this E the rounding error of det is no longer small against its 1e-5 cutoff
-		const float e_limit = 6.0f / dlen;
-		const float rho_pad = sc.bvh_rho * R + slop;
-
-		int sp = 0;
-		int node = __float_as_int(r0.w);
-		for (;;)
-		{
-			if (node >= 0)
-			{
-				const float4 q0 = sc.bvh_nodes[4 * (size_t)node], q1 = sc.bvh_nodes[4 * (size_t)node + 1];
-				const float4 q2 = sc.bvh_nodes[4 * (size_t)node + 2], q3 = sc.bvh_nodes[4 * (size_t)node + 3];
-				float pad_l = q3.z <= e_limit ? q3.z * padc + slop : INFINITY;
-				float pad_r = q3.w <= e_limit ? q3.w * padc + slop : INFINITY;
-				if (sc.bvh_rho > 0.0f)
-				{
-					pad_l = fminf(pad_l, rho_pad);
-					pad_r = fminf(pad_r, rho_pad);
-				}
-				float lo_l, lo_r;
-				const bool vl = bvh_box(ro, inv, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, pad_l, best, lo_l);
-				const bool vr = bvh_box(ro, inv, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, pad_r, best, lo_r);
-				const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
-				if (vl & vr)
-				{
-					const bool left_first = !(lo_r < lo_l);
-					stack[sp++][tid] = left_first ? right : left;
-					node = left_first ? left : right;
-					continue;
-				}
-				if (vl) { node = left; continue; }
-				if (vr) { node = right; continue; }
-			}
-			else
-			{
-				const int leaf = ~node;
-				const int first = leaf >> 4, count = (leaf & 15) + 1;
-				for (int k = 0; k < count; ++k)
-				{
-					const float4 g0 = sc.bvh_tris[3 * (size_t)(first + k)];
-					const float4 g1 = sc.bvh_tris[3 * (size_t)(first + k) + 1];
-					const float4 g2 = sc.bvh_tris[3 * (size_t)(first + k) + 2];
-					const F3 p0 = f3(g0.x, g0.y, g0.z), e0 = f3(g0.w, g1.x, g1.y), e1 = f3(g1.z, g1.w, g2.x);
-					const int pos = __float_as_int(g2.y);
-					F3 h = cross(d, e1);
-					float det = dot(e0, h);
-					if (det > -0.00001f && det < 0.00001f) continue;
-					float f = 1.0f / det;
-					F3 s = o - p0;
-					float u = f * dot(s, h);
-					if (u < 0.0f || u > 1.0f) continue;
-					F3 q = cross(s, e0);
-					float v = f * dot(d, q);
-					if (v < 0.0f || u + v > 1.0f) continue;
-					float t0 = f * dot(e1, q);
-					if (t0 > tmin && (t0 < best || (t0 == best && best_pos >= 0 && pos < best_pos)))
-					{
-						best = t0;
-						best_pos = pos;
-					}
-				}
-			}
-			if (sp == 0) break;
-			node = stack[--sp][tid];
-		}
-	}
-	if (best_pos >= 0)
-	{
-		closest = best;
-		id = sc.S + best_pos;
-	}
-}
-
-// Wave-cooperative walk of the same hierarchies.  Rays of a wave need very different amounts
+// The walk is wave-cooperative.  Rays of a wave need very different amounts
 // of traversal (many miss every box, some cross the whole mesh), so a per-lane walk leaves
 // most lanes idle.  Here every lane of the wave is a WORKER with its own depth-first stack;
 // a worker without work takes (1) the next box its own ray hit, else (2) the OLDEST entry —
@@ -767,7 +660,7 @@ __device__ __forceinline__ void triangles_steal(const SceneDev &sc, int (*stack)
 				if (!__ballot(boxes != 0)) break;
 				continue; // a box without triangles was skipped; its lane tries its next box
 			}
-			if (__popcll(idle) >= ((sc.bvh_steal >> 8) & 255))
+			if (__popcll(idle) >= sc.bvh_steal_min_idle)
 			{
 				const unsigned long long donors = __ballot(sp > bot);
 				if (donors)
@@ -779,8 +672,8 @@ __device__ __forceinline__ void triangles_steal(const SceneDev &sc, int (*stack)
 						const int k = __popcll(donors & below);
 						if (k < m)
 						{
-							if (sc.bvh_steal & 2) { w.mail[base + k] = make_int2(stack[sp - 1][col], (cur - base) | (cur_box << 8)); --sp; }
-							else { w.mail[base + k] = make_int2(stack[bot][col], (cur - base) | (cur_box << 8)); ++bot; }
+							w.mail[base + k] = make_int2(stack[bot][col], (cur - base) | (cur_box << 8));
+							++bot;
 							if (sp == bot) sp = bot = 0;
 						}
 					}
@@ -982,7 +875,7 @@ __global__ __launch_bounds__(256) void k_render(const RenderParams p)
 	__shared__ TriTiles s_tiles[MESH && STATS ? 4 : 1]; // counting build: sequential staged loop, one per wave
 	__shared__ unsigned long long s_best[MESH && !STATS ? 4 : 1][64];
 	__shared__ int s_stack[MESH && !STATS ? WBRT_BVH_STACK : 1][256]; // one column per thread
-	__shared__ StealLds s_steal[MESH && !STATS ? 1 : 1];
+	__shared__ StealLds s_steal[1];
 	Counters<STATS> ctr;
 	const SceneDev &sc = p.sc;
 	long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1042,11 +935,7 @@ __global__ __launch_bounds__(256) void k_render(const RenderParams p)
 			{
 				if (trace) boxes_and_triangles<STATS>(sc, s_tiles[threadIdx.x >> 6], L.o, L.d, t, id, ctr);
 			}
-			else if (sc.bvh_nodes && sc.bvh_steal) triangles_steal(sc, s_stack, s_steal[0], trace, L.o, L.d, t, id);
-			else if (sc.bvh_nodes)
-			{
-				if (trace) triangles_bvh(sc, s_stack, L.o, L.d, t, id);
-			}
+			else if (sc.bvh_nodes) triangles_steal(sc, s_stack, s_steal[0], trace, L.o, L.d, t, id);
 			else triangles_cooperative(sc, s_best[threadIdx.x >> 6], trace, L.o, L.d, t, id);
 		}
 		if (MESH && !alive) continue;
