@@ -301,12 +301,30 @@ def host_kat():
          colour_in=vals, colour_bgr=bgr, bmp_in=img, bmp_file=bmp_bytes)
 
 
+def mesh_large():
+    """Mesh configuration at sizes the reference kernel still finishes in minutes on the host:
+    a 480x270, 2 spp image + ids, and the primary ids of the full 1920x1080 frame."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import util
+    scene = util.scene_main_cpp_with_mesh("f1_car")
+    image_case("maincpp_f1car_480x270_s2_b4", scene, pkg.camera_main_cpp(480, 2, 50), 4, 13)
+    cam = pkg.camera_main_cpp(1920, 1, 50)
+    bw, bh = pkg.set_blocks(cam, 4)
+    seeds = pkg.make_seeds(bw * bh, 0x5EED)
+    ids = orc.Reference(scene).primary_ids(cam, seeds)
+    print("1920x1080 mesh primary ids: %d distinct, %d misses" % (len(np.unique(ids)), int((ids < 0).sum())))
+    save("ids_maincpp_f1car_1920x1080_b4.npz", ids=ids.astype(np.int16), seed=np.array([0x5EED], dtype=np.uint64))
+
+
 def main():
     if not orc.have_ref():
         raise SystemExit("oracle/_ref/libwbref.so missing: run `make -C oracle ref` where /root/reference exists")
     sizes = (C.c_int * 8)()
     ref.wbref_sizes(sizes)
     assert list(sizes) == [12, 24, 40, 64, 28, 120, 36, 56], list(sizes)
+    if "--mesh-large" in sys.argv:
+        mesh_large()
+        return
     if "--host-only" in sys.argv:
         host_kat()
         return
@@ -335,6 +353,7 @@ def main():
     vals, counts = np.unique(ids, return_counts=True)
     print("1280x720 primary ids:", dict(zip(vals.tolist(), counts.tolist())))
     save("ids_readme_1280x720_b4.npz", ids=ids.astype(np.int8), seed=np.array([0x5EED], dtype=np.uint64))
+    mesh_large()
 
 
 if __name__ == "__main__":
