@@ -192,6 +192,29 @@ def test_mesh_modes_identical(gpu_ctx, name):
         assert np.array_equal(gpu_ctx.primary_ids(cam), O.primary_ids(cam, seeds))
 
 
+def test_mesh_goldens_at_size(gpu_ctx):
+    """BASELINE configs[2] (main.cpp spheres + f1_car mesh) against the reference kernel's own
+    output at sizes its host build still finishes: 480x270 image + ids, 1920x1080 primary ids.
+    Every mesh mode must give the reference's ids; the image must stay within the tolerance."""
+    scene = scene_main_cpp_with_mesh("f1_car")
+    z = golden("img_maincpp_f1car_480x270_s2_b4.npz")
+    meta = golden_meta(z)
+    cam = camera_by_meta(meta)
+    _setup(gpu_ctx, scene, cam, meta["blocks"], meta["seed"])
+    assert np.array_equal(gpu_ctx.primary_ids(cam), z["ids"])
+    try:
+        for mode in (pkg.MESH_LOOP, pkg.MESH_BVH_STRICT, pkg.MESH_BVH):
+            gpu_ctx.set_mesh_mode(mode)
+            mae, psnr = image_error(gpu_ctx.render_frame(cam), z["image"])
+            assert mae <= 1e-3 and psnr >= 40.0, (mode, mae, psnr)
+    finally:
+        gpu_ctx.set_mesh_mode(pkg.MESH_BVH)
+    full = golden("ids_maincpp_f1car_1920x1080_b4.npz")
+    cam = pkg.camera_main_cpp(1920, 1, 50)
+    _setup(gpu_ctx, scene, cam, 4, int(full["seed"][0]))
+    assert np.array_equal(gpu_ctx.primary_ids(cam), full["ids"].astype(np.int32))
+
+
 def test_block_entry_point_equals_frame_region(gpu_ctx):
     scene, cam = pkg.scene_readme(), pkg.camera_readme(160, 4, 50)
     _setup(gpu_ctx, scene, cam, 4, 12)
