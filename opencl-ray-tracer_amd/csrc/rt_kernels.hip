@@ -1233,7 +1233,13 @@ inline unsigned grid_for(const RenderParams &p)
 hipError_t wbrt_launch_render(const RenderParams &p, hipStream_t stream)
 {
 	if (p.sc.B > 0) hipLaunchKernelGGL((k_render<false, true>), dim3(grid_for(p)), dim3(256), 0, stream, p);
-	else hipLaunchKernelGGL((k_render<false, false>), dim3(grid_for(p)), dim3(256), 0, stream, p);
+	else
+	{
+		// one wave per workgroup: no LDS here, and single waves fill freed slots soonest
+		const int block = 64;
+		const long long total = (long long)p.bsx * p.bsy * p.nbx * p.nby;
+		hipLaunchKernelGGL((k_render<false, false>), dim3((unsigned)((total + block - 1) / block)), dim3(block), 0, stream, p);
+	}
 	return hipGetLastError();
 }
 
