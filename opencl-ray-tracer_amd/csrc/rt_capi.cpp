@@ -67,6 +67,7 @@ struct wbrt_context
 	DevBuf box_min, box_max, box_range;
 	DevBuf bvh_nodes[2], bvh_tris[2], bvh_roots[2]; // [0] plain surface-area trees, [1] built for the strict margins
 	const float4 *bvh_ptr[2][3] = {};
+	int bvh_depth[2] = {0, 0};
 	int mesh_mode = WBRT_MESH_BVH;
 	int bvh_steal_min_idle = 8;
 	float bvh_rho = 1e-4f; // WBRT_MESH_BVH: box margin as a fraction of the ray's distance bound
@@ -135,6 +136,7 @@ int make_params(wbrt_context *ctx, const wbrt_camera *cam, bool whole_frame, Ren
 		p.sc.bvh_nodes = ctx->bvh_ptr[variant][0];
 		p.sc.bvh_tris = ctx->bvh_ptr[variant][1];
 		p.sc.bvh_roots = ctx->bvh_ptr[variant][2];
+		p.sc.bvh_box_slots = WBRT_BVH_STACK - ctx->bvh_depth[variant] + 1;
 	}
 	p.sc.bvh_rho = ctx->mesh_mode == WBRT_MESH_BVH ? ctx->bvh_rho : 0.0f;
 	p.sc.bvh_steal_min_idle = ctx->bvh_steal_min_idle;
@@ -322,6 +324,7 @@ int wbrt_upload_scene(wbrt_context *ctx, const wbrt_sphere *spheres, int32_t S,
 		ctx->bvh_ptr[variant][0] = (const float4 *)ctx->bvh_nodes[variant].p;
 		ctx->bvh_ptr[variant][1] = (const float4 *)ctx->bvh_tris[variant].p;
 		ctx->bvh_ptr[variant][2] = (const float4 *)ctx->bvh_roots[variant].p;
+		ctx->bvh_depth[variant] = bvh.depth;
 	}
 	ctx->have_bvh = Tg > 0;
 #undef UP

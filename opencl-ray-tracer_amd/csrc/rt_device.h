@@ -46,6 +46,7 @@ struct SceneDev
 	const float4 *bvh_tris;   // 3 per leaf slot: tri_geom layout, fourth word of the last float4 = position in the grouped order
 	const float4 *bvh_roots;  // 2 per box: min.xyz ref | max.xyz E   (E < 0: box without triangles)
 	float bvh_rho;
+	int bvh_box_slots;        // stack entries free for queued boxes: WBRT_BVH_STACK - tree depth + 1
 	int bvh_steal_min_idle;   // idle lanes of a wave needed before a hand-over round is run
 	// sky: skyw*skyh texels + skyw+1 zero guard texels, 3 floats each
 	const float *sky;

@@ -37,6 +37,20 @@ __device__ __forceinline__ F3 unit(F3 a) { return a / sqrtf(dot(a, a)); }
 __device__ __forceinline__ F3 ld3(const float *p) { return f3(p[0], p[1], p[2]); }
 
 // ---------------------------------------------------------------- counters
+// Wave-uniform read of read-only scene data (same index in every lane): going through the
+// constant address space makes it a scalar load into SGPRs instead of a 64-lane vector load of
+// one address.  Only for buffers no kernel writes.
+typedef float wbrt_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 uniform_ld(const float4 *p, int i)
+{
+#if __HIP_DEVICE_COMPILE__
+	const wbrt_v4f v = ((const __attribute__((address_space(4))) wbrt_v4f *)p)[i];
+	return make_float4(v.x, v.y, v.z, v.w);
+#else
+	return p[i]; // host pass of the compiler only; never executed
+#endif
+}
+
 template <bool ON> struct Counters;
 template <> struct Counters<false>
 {
@@ -280,12 +294,12 @@ __device__ __forceinline__ bool spheres_fast(const SceneDev &sc, F3 o, F3 d, flo
 	float best_n = INFINITY, best_m = 0.0f, best_hb = 0.0f, best_disc = 0.0f;
 	bool best_second = false;
 	int id = -1;
-	float4 g_next = sc.S > 0 ? sc.sph_geom[0] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	float4 g_next = sc.S > 0 ? uniform_ld(sc.sph_geom, 0) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 	for (int i = 0; i < sc.S; ++i)
 	{
 		// the next sphere's scalar load is issued before this sphere's arithmetic
 		const float4 g = g_next;
-		g_next = sc.sph_geom[i + 1 < sc.S ? i + 1 : i];
+		g_next = uniform_ld(sc.sph_geom, i + 1 < sc.S ? i + 1 : i);
 		F3 oc = o - f3(g.x, g.y, g.z);
 		float hb = dot(oc, d);
 		float cc = dot(oc, oc) - g.w;
@@ -381,7 +395,7 @@ __device__ __forceinline__ void boxes_and_triangles(const SceneDev &sc, TriTiles
 	const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(active >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)active, 0u));
 	for (int b = 0; b < sc.B; ++b)
 	{
-		const float4 mn = sc.box_min[b], mx = sc.box_max[b];
+		const float4 mn = uniform_ld(sc.box_min, b), mx = uniform_ld(sc.box_max, b);
 		float tx1 = (mn.x - o.x) * ix, tx2 = (mx.x - o.x) * ix;
 		float lo = fminf(tx1, tx2), hi = fmaxf(tx1, tx2);
 		float ty1 = (mn.y - o.y) * iy, ty2 = (mx.y - o.y) * iy;
@@ -473,7 +487,7 @@ __device__ __forceinline__ void triangles_cooperative(const SceneDev &sc, unsign
 	const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
 	for (int b = 0; b < sc.B; ++b)
 	{
-		const float4 mn = sc.box_min[b], mx = sc.box_max[b];
+		const float4 mn = uniform_ld(sc.box_min, b), mx = uniform_ld(sc.box_max, b);
 		float tx1 = (mn.x - o.x) * ix, tx2 = (mx.x - o.x) * ix;
 		float lo = fminf(tx1, tx2), hi = fmaxf(tx1, tx2);
 		float ty1 = (mn.y - o.y) * iy, ty2 = (mx.y - o.y) * iy;
@@ -589,6 +603,7 @@ __device__ __forceinline__ void bvh_load_ray(const StealLds &w, int slot, BvhRay
 
 // margins of ray r against the hierarchy of `box`; returns its root reference (INT_MIN: no triangles)
 #define BVH_NONE ((int)0x80000000)
+#define BVH_BOX_TAG 0x40000000
 __device__ __forceinline__ int bvh_enter_box(const SceneDev &sc, int box, BvhRay &r)
 {
 	const float4 r0 = sc.bvh_roots[2 * box], r1 = sc.bvh_roots[2 * box + 1];
@@ -616,14 +631,18 @@ __device__ __forceinline__ void triangles_steal(const SceneDev &sc, int (*stack)
 	BvhRay r;
 	bvh_load_ray(w, col, r);
 	const unsigned long long below = (1ull << lane) - 1ull;
-	for (int b0 = 0; b0 < sc.B; b0 += 64)
+	// Boxes whose slab test passes for the lane's own ray are queued on the lane's stack as
+	// BVH_BOX_TAG | box; an entry turns into that box's root when a worker takes it.  A stack
+	// has room for bvh_box_slots of them on top of one root-to-leaf path; a lane that hit more
+	// boxes queues the rest in a further pass.
+	int start = 0; // first box this lane has not queued yet
+	int node = BVH_NONE, sp = 0, bot = 0, cur = col, cur_box = 0;
+	for (;;)
 	{
-		// boxes (of this group of 64) whose slab test passes for the lane's own ray
-		unsigned long long boxes = 0;
-		const int nb = sc.B - b0 < 64 ? sc.B - b0 : 64;
-		for (int b = 0; b < nb; ++b)
+		int resume = sc.B;
+		for (int b = 0; b < sc.B; ++b)
 		{
-			const float4 mn = sc.box_min[b0 + b], mx = sc.box_max[b0 + b];
+			const float4 mn = uniform_ld(sc.box_min, b), mx = uniform_ld(sc.box_max, b);
 			float tx1 = (mn.x - o.x) * r.inv.x, tx2 = (mx.x - o.x) * r.inv.x;
 			float lo = fminf(tx1, tx2), hi = fmaxf(tx1, tx2);
 			float ty1 = (mn.y - o.y) * r.inv.y, ty2 = (mx.y - o.y) * r.inv.y;
@@ -632,67 +651,67 @@ __device__ __forceinline__ void triangles_steal(const SceneDev &sc, int (*stack)
 			float tz1 = (mn.z - o.z) * r.inv.z, tz2 = (mx.z - o.z) * r.inv.z;
 			lo = fmaxf(lo, fminf(tz1, tz2));
 			hi = fminf(hi, fmaxf(tz1, tz2));
-			if (trace && hi > fmaxf(lo, 0.0f)) boxes |= 1ull << b;
+			if (trace && b >= start && hi > fmaxf(lo, 0.0f))
+			{
+				if (sp < sc.bvh_box_slots) stack[sp++][col] = BVH_BOX_TAG | b;
+				else if (resume == sc.B) resume = b;
+			}
 		}
-		if (!__ballot(boxes != 0)) continue;
+		if (!__ballot(sp > 0)) break;
 
-		int node = BVH_NONE, sp = 0, bot = 0, cur = col, cur_box = 0;
 		for (;;)
 		{
-			if (node == BVH_NONE)
+			if (node == BVH_NONE && sp > bot)
 			{
-				if (sp > bot)
+				node = stack[--sp][col];
+				if (sp == bot) sp = bot = 0;
+				if (node >= BVH_BOX_TAG) // own entries are queued and taken with the own ray loaded
 				{
-					node = stack[--sp][col];
-					if (sp == bot) sp = bot = 0;
-				}
-				else if (boxes)
-				{
-					cur_box = b0 + __builtin_ctzll(boxes);
-					boxes &= boxes - 1;
-					if (cur != col) { cur = col; bvh_load_ray(w, col, r); }
+					cur_box = node - BVH_BOX_TAG;
 					node = bvh_enter_box(sc, cur_box, r);
 				}
 			}
 			const unsigned long long idle = __ballot(node == BVH_NONE);
+			const unsigned long long donors = __ballot(sp > bot);
 			if (idle == ~0ull)
 			{
-				if (!__ballot(boxes != 0)) break;
-				continue; // a box without triangles was skipped; its lane tries its next box
+				if (!donors) break;
+				continue; // a box without triangles was skipped; its lane takes its next entry
 			}
-			if (__popcll(idle) >= sc.bvh_steal_min_idle)
+			if (donors && __popcll(idle) >= sc.bvh_steal_min_idle)
 			{
-				const unsigned long long donors = __ballot(sp > bot);
-				if (donors)
+				const int nd = __popcll(donors), ni = __popcll(idle);
+				const int m = nd < ni ? nd : ni;
+				if (((donors >> lane) & 1ull) != 0)
 				{
-					const int nd = __popcll(donors), ni = __popcll(idle);
-					const int m = nd < ni ? nd : ni;
-					if (((donors >> lane) & 1ull) != 0)
+					const int k = __popcll(donors & below);
+					if (k < m)
 					{
-						const int k = __popcll(donors & below);
-						if (k < m)
-						{
-							w.mail[base + k] = make_int2(stack[bot][col], (cur - base) | (cur_box << 8));
-							++bot;
-							if (sp == bot) sp = bot = 0;
-						}
+						w.mail[base + k] = make_int2(stack[bot][col], (cur - base) | (cur_box << 8));
+						++bot;
+						if (sp == bot) sp = bot = 0;
 					}
-					__builtin_amdgcn_wave_barrier();
-					if (((idle >> lane) & 1ull) != 0)
-					{
-						const int k = __popcll(idle & below);
-						if (k < m)
-						{
-							const int2 got = w.mail[base + k];
-							node = got.x;
-							cur = base + (got.y & 255);
-							cur_box = got.y >> 8;
-							bvh_load_ray(w, cur, r);
-							(void)bvh_enter_box(sc, cur_box, r);
-						}
-					}
-					__builtin_amdgcn_wave_barrier();
 				}
+				__builtin_amdgcn_wave_barrier();
+				if (((idle >> lane) & 1ull) != 0)
+				{
+					const int k = __popcll(idle & below);
+					if (k < m)
+					{
+						const int2 got = w.mail[base + k];
+						node = got.x;
+						cur = base + (got.y & 255);
+						cur_box = got.y >> 8;
+						bvh_load_ray(w, cur, r);
+						if (node >= BVH_BOX_TAG)
+						{
+							cur_box = node - BVH_BOX_TAG;
+							node = bvh_enter_box(sc, cur_box, r);
+						}
+						else (void)bvh_enter_box(sc, cur_box, r);
+					}
+				}
+				__builtin_amdgcn_wave_barrier();
 			}
 			if (node == BVH_NONE) continue;
 			if (node >= 0)
@@ -741,9 +760,11 @@ __device__ __forceinline__ void triangles_steal(const SceneDev &sc, int (*stack)
 					atomicMin(&w.best[cur], ((unsigned long long)__float_as_uint(t0) << 32) | (unsigned)__float_as_int(g2.y));
 			}
 		}
-		// the next group of boxes starts from the own ray again
+		// every stack is empty again; lanes that could not queue all their boxes go round once more
 		if (cur != col) { cur = col; bvh_load_ray(w, col, r); }
+		start = resume;
 		__builtin_amdgcn_wave_barrier();
+		if (!__ballot(resume < sc.B)) break;
 	}
 	__builtin_amdgcn_wave_barrier();
 	const unsigned long long k = w.best[col];

@@ -166,12 +166,32 @@ def _awkward_mesh_scene():
     return pkg.Scene(spheres=pkg.scene_main_cpp().spheres, triangles=tris, boxes=boxes)
 
 
-@pytest.mark.parametrize("name", ["awkward", "f1_car", "stress"])
+def _many_boxes_scene():
+    """48 bounding boxes that all cover the same volume, triangles dealt round-robin: every ray
+    that enters the volume hits more boxes than a lane's stack can queue at once."""
+    rs = np.random.RandomState(78)
+    n = 48 * 25
+    centers = rs.uniform([-1.0, -0.3, -2.0], [1.0, 0.8, -0.8], (n, 3))
+    soup = (centers[:, None, :] + rs.uniform(-0.15, 0.15, (n, 3, 3))).astype(np.float32).reshape(-1, 9)
+    tris, mn, mx = triangles_from_soup(soup, (1, 1, 1), (0, 0, 0), pkg.material((0.6, 0.7, 0.8), 0.1, 0.0, pkg.METAL), 0)
+    arr = np.frombuffer(tris, dtype=np.float32).reshape(n, 16)
+    arr[:, 9:12] = rs.uniform(0.2, 1.0, (n, 3))
+    arr.view(np.int32)[:, 14] = rs.randint(0, 2, n)
+    arr.view(np.int32)[:, 15] = np.arange(n) % 48
+    boxes = (pkg.BoundingBox * 48)()
+    for b in range(48):
+        boxes[b] = pkg.BoundingBox(b, pkg.vec3(-1.3, -0.6, -2.3), pkg.vec3(1.3, 1.1, -0.5))
+    return pkg.Scene(spheres=pkg.scene_main_cpp().spheres, triangles=tris, boxes=boxes)
+
+
+@pytest.mark.parametrize("name", ["awkward", "many_boxes", "f1_car", "stress"])
 def test_mesh_modes_identical(gpu_ctx, name):
     """The hierarchy walks (strict and default margins) must reproduce the per-box triangle loop,
     and the loop must reproduce the oracle."""
     if name == "awkward":
         scene, cam, check_oracle = _awkward_mesh_scene(), pkg.camera_main_cpp(192, 6, 50), True
+    elif name == "many_boxes":
+        scene, cam, check_oracle = _many_boxes_scene(), pkg.camera_main_cpp(160, 4, 50), True
     elif name == "f1_car":
         scene, cam, check_oracle = scene_main_cpp_with_mesh("f1_car"), pkg.camera_main_cpp(320, 6, 50), False
     else:
