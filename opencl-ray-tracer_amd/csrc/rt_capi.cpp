@@ -130,7 +130,9 @@ int make_params(wbrt_context *ctx, const wbrt_camera *cam, bool whole_frame, Ren
 	}
 	p.seeds = (const uint32_t *)ctx->seeds.p;
 	p.sc = ctx->sc;
-	if (ctx->mesh_mode != WBRT_MESH_LOOP && ctx->have_bvh)
+	// strict margins on a small mesh widen every box to the whole mesh: the cooperative loop is faster there
+	const bool strict_small = ctx->mesh_mode == WBRT_MESH_BVH_STRICT && ctx->sc.T <= 4096;
+	if (ctx->mesh_mode != WBRT_MESH_LOOP && ctx->have_bvh && !strict_small)
 	{
 		const int variant = ctx->mesh_mode == WBRT_MESH_BVH_STRICT ? 1 : 0;
 		p.sc.bvh_nodes = ctx->bvh_ptr[variant][0];
