@@ -234,6 +234,45 @@ void wbrt_build_bvh(const float4 *tri_geom, const int2 *ranges, int B, bool spli
 	}
 }
 
+// Appends one more hierarchy, over the SPHERES, to bvh (its root becomes bvh.roots.back()).
+// sph_geom: center.xyz, radius^2; radius: the radii (negative ones are legal: the reference only
+// uses radius^2 for the test).  Leaves reference positions in the sphere array; nodes carry the
+// largest |radius| below each child where triangle nodes carry E.
+//
+// The reference tests every sphere (gpu_kernel.cl:361-371) and keeps the nearest accepted root,
+// the LATER sphere winning ties (its bounds are inclusive, gpu_kernel.cl:466-473).  That winner
+// is the minimum of (root, -index) over all spheres whose float test accepts, whatever the
+// order.  The float test accepts only if the ray passes within sqrt(r^2 + ~18u (|o-c|^2 + r^2))
+// of the centre, and the root it returns lies within that distance of the centre too, so
+// boxes widened by 2e-3 (|o - c| + r) for every sphere inside never hide a sphere it would accept.
+void wbrt_append_sphere_tree(const float4 *sph_geom, const float *radius, int S, WbrtBvh &bvh)
+{
+	std::vector<Prim> prims((size_t)S);
+	for (int i = 0; i < S; ++i)
+	{
+		Prim &p = prims[(size_t)i];
+		const double r = std::fabs((double)radius[i]);
+		const double c[3] = { sph_geom[i].x, sph_geom[i].y, sph_geom[i].z };
+		for (int a = 0; a < 3; ++a) { p.b.mn[a] = c[a] - r; p.b.mx[a] = c[a] + r; p.c[a] = c[a]; }
+		p.e = r;
+		p.index = i;
+	}
+	WbrtBvhRoot root{};
+	Builder bl;
+	bl.prims = std::move(prims);
+	bl.out = &bvh;
+	bl.depth_limit = WBRT_BVH_STACK;
+	bl.split_by_e = true; // a few huge spheres (a ground sphere) must not widen every box
+	Bounds rb;
+	double re;
+	root.ref = bl.build(0, S, 0, rb, re);
+	for (int a = 0; a < 3; ++a) { root.mn[a] = round_down(rb.mn[a]); root.mx[a] = round_up(rb.mx[a]); }
+	root.e = round_up(re * 1.000001);
+	root.empty = 0;
+	bvh.roots.push_back(root);
+	bvh.depth = std::max(bvh.depth, bl.max_depth);
+}
+
 // Test hook (not in the public header): runs the builder on host arrays and copies the result
 // out.  tri_geom: 12 floats per triangle in the device layout; ranges: first,last per box;
 // nodes_out: 16 floats per node; roots_out: 8 floats per box (min.xyz ref | max.xyz E, E < 0 =

@@ -4,6 +4,7 @@
 #include "../../include/ocl_rt_amd.h"
 #include "rt_device.h"
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -75,7 +76,8 @@ struct wbrt_context
 	int lpt = 1;        // longest-first scheduling from a pilot pass
 	int pilot_spp = 4;
 	SceneDev sc{};
-	bool have_scene = false, have_sky = false, have_bvh = false;
+	bool have_scene = false, have_sky = false, have_bvh = false, have_sphere_tree = false;
+	int sphere_tree_min = 128; // sphere count from which the render build walks a sphere hierarchy
 	size_t n_seeds = 0;
 	bool timing = false;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -131,7 +133,7 @@ int make_params(wbrt_context *ctx, const wbrt_camera *cam, bool whole_frame, Ren
 	p.seeds = (const uint32_t *)ctx->seeds.p;
 	p.sc = ctx->sc;
 	// strict margins on a small mesh widen every box to the whole mesh: the cooperative loop is faster there
-	const bool strict_small = ctx->mesh_mode == WBRT_MESH_BVH_STRICT && ctx->sc.T <= 4096;
+	const bool strict_small = ctx->mesh_mode == WBRT_MESH_BVH_STRICT && ctx->sc.T <= 4096 && !ctx->have_sphere_tree;
 	if (ctx->mesh_mode != WBRT_MESH_LOOP && ctx->have_bvh && !strict_small)
 	{
 		const int variant = ctx->mesh_mode == WBRT_MESH_BVH_STRICT ? 1 : 0;
@@ -139,6 +141,7 @@ int make_params(wbrt_context *ctx, const wbrt_camera *cam, bool whole_frame, Ren
 		p.sc.bvh_tris = ctx->bvh_ptr[variant][1];
 		p.sc.bvh_roots = ctx->bvh_ptr[variant][2];
 		p.sc.bvh_box_slots = WBRT_BVH_STACK - ctx->bvh_depth[variant] + 1;
+		p.sc.sph_tree = ctx->have_sphere_tree ? 1 : 0;
 	}
 	p.sc.bvh_rho = ctx->mesh_mode == WBRT_MESH_BVH ? ctx->bvh_rho : 0.0f;
 	p.sc.bvh_steal_min_idle = ctx->bvh_steal_min_idle;
@@ -207,6 +210,7 @@ int wbrt_create(int device_ordinal, wbrt_context **out)
 	// tuning knobs for experiments (not part of the ABI contract)
 	if (const char *v = std::getenv("WBRT_LPT")) ctx->lpt = std::atoi(v) != 0;
 	if (const char *v = std::getenv("WBRT_MESH_MODE")) { int m = std::atoi(v); if (m >= 0 && m <= 2) ctx->mesh_mode = m; }
+	if (const char *v = std::getenv("WBRT_SPHERE_TREE_MIN")) ctx->sphere_tree_min = std::atoi(v);
 	if (const char *v = std::getenv("WBRT_BVH_MIN_IDLE")) ctx->bvh_steal_min_idle = std::atoi(v);
 	if (const char *v = std::getenv("WBRT_BVH_RHO")) { float r = (float)std::atof(v); if (r > 0.0f) ctx->bvh_rho = r; }
 	if (const char *v = std::getenv("WBRT_PILOT_SPP")) ctx->pilot_spp = std::atoi(v) > 0 ? std::atoi(v) : 4;
@@ -297,30 +301,45 @@ int wbrt_upload_scene(wbrt_context *ctx, const wbrt_sphere *spheres, int32_t S,
 	UP(sph_geom, geom); UP(sph_radius, radius); UP(sph_mat_a, mat_a); UP(sph_mat_b, mat_b);
 	UP(tri_geom, tgeom); UP(tri_mat_a, tmat_a); UP(tri_mat_b, tmat_b); UP(tri_orig, torig);
 	UP(box_min, bmin); UP(box_max, bmax); UP(box_range, brange);
-	// triangle hierarchies (render build only; the counting and primary-id builds keep the loop)
-	for (int variant = 0; variant < 2 && Tg > 0; ++variant)
+	// A hierarchy over the spheres pays off for large sphere counts; it needs finite, moderate
+	// coordinates (the kernel's margins assume no overflow in the reference's sphere test).
+	bool sphere_tree = S >= ctx->sphere_tree_min;
+	for (int i = 0; i < S && sphere_tree; ++i)
+	{
+		const float v[4] = { spheres[i].center.x, spheres[i].center.y, spheres[i].center.z, spheres[i].radius };
+		for (float x : v) if (!(std::fabs(x) < 1e8f)) sphere_tree = false;
+	}
+	// hierarchies (render build only; the counting and primary-id builds keep the loops)
+	for (int variant = 0; variant < 2 && (Tg > 0 || sphere_tree); ++variant)
 	{
 		WbrtBvh bvh;
 		wbrt_build_bvh(tgeom.data(), brange.data(), B, variant == 1, bvh);
+		const size_t tri_slots = bvh.tri_index.size();
+		if (sphere_tree) wbrt_append_sphere_tree(geom.data(), radius.data(), S, bvh);
 		static_assert(sizeof(WbrtBvhNode) == 4 * sizeof(float4), "node layout");
-		std::vector<float4> bnodes(bvh.nodes.size() * 4), btris(bvh.tri_index.size() * 3), broots((size_t)B * 2);
+		std::vector<float4> bnodes(bvh.nodes.size() * 4), btris(bvh.tri_index.size() * 3), broots(bvh.roots.size() * 2);
 		if (!bvh.nodes.empty()) std::memcpy(bnodes.data(), bvh.nodes.data(), bvh.nodes.size() * sizeof(WbrtBvhNode));
 		for (size_t k = 0; k < bvh.tri_index.size(); ++k)
 		{
 			const size_t src = (size_t)bvh.tri_index[k];
-			btris[3 * k + 0] = tgeom[3 * src + 0];
-			btris[3 * k + 1] = tgeom[3 * src + 1];
-			float4 last = tgeom[3 * src + 2];
 			const int pos = bvh.tri_index[k];
+			float4 last = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+			if (k < tri_slots)
+			{
+				btris[3 * k + 0] = tgeom[3 * src + 0];
+				btris[3 * k + 1] = tgeom[3 * src + 1];
+				last = tgeom[3 * src + 2];
+			}
+			else btris[3 * k + 0] = geom[src]; // sphere slot: center.xyz, radius^2
 			std::memcpy(&last.y, &pos, 4);
 			btris[3 * k + 2] = last;
 		}
-		for (int b = 0; b < B; ++b)
+		for (size_t b = 0; b < bvh.roots.size(); ++b)
 		{
-			const WbrtBvhRoot &r = bvh.roots[(size_t)b];
+			const WbrtBvhRoot &r = bvh.roots[b];
 			float ref; std::memcpy(&ref, &r.ref, 4);
-			broots[2 * (size_t)b] = make_float4(r.mn[0], r.mn[1], r.mn[2], ref);
-			broots[2 * (size_t)b + 1] = make_float4(r.mx[0], r.mx[1], r.mx[2], r.empty ? -1.0f : r.e);
+			broots[2 * b] = make_float4(r.mn[0], r.mn[1], r.mn[2], ref);
+			broots[2 * b + 1] = make_float4(r.mx[0], r.mx[1], r.mx[2], r.empty ? -1.0f : r.e);
 		}
 		UP(bvh_nodes[variant], bnodes); UP(bvh_tris[variant], btris); UP(bvh_roots[variant], broots);
 		ctx->bvh_ptr[variant][0] = (const float4 *)ctx->bvh_nodes[variant].p;
@@ -328,11 +347,13 @@ int wbrt_upload_scene(wbrt_context *ctx, const wbrt_sphere *spheres, int32_t S,
 		ctx->bvh_ptr[variant][2] = (const float4 *)ctx->bvh_roots[variant].p;
 		ctx->bvh_depth[variant] = bvh.depth;
 	}
-	ctx->have_bvh = Tg > 0;
+	ctx->have_bvh = Tg > 0 || sphere_tree;
+	ctx->have_sphere_tree = sphere_tree;
 #undef UP
 	SceneDev &sc = ctx->sc;
 	sc.bvh_nodes = sc.bvh_tris = sc.bvh_roots = nullptr; // chosen per render (make_params)
 	sc.bvh_rho = 0.0f;
+	sc.sph_tree = 0;
 	sc.sph_geom = (const float4 *)ctx->sph_geom.p; sc.sph_radius = (const float *)ctx->sph_radius.p;
 	sc.sph_mat_a = (const float4 *)ctx->sph_mat_a.p; sc.sph_mat_b = (const float2 *)ctx->sph_mat_b.p;
 	sc.S = S;

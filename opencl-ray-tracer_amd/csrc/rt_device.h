@@ -46,6 +46,7 @@ struct SceneDev
 	const float4 *bvh_tris;   // 3 per leaf slot: tri_geom layout, fourth word of the last float4 = position in the grouped order
 	const float4 *bvh_roots;  // 2 per box: min.xyz ref | max.xyz E   (E < 0: box without triangles)
 	float bvh_rho;
+	int sph_tree;             // 1: bvh_roots[B] is a hierarchy over the spheres (leaf slot: center.xyz r^2 | - | - index - -)
 	int bvh_box_slots;        // stack entries free for queued boxes: WBRT_BVH_STACK - tree depth + 1
 	int bvh_steal_min_idle;   // idle lanes of a wave needed before a hand-over round is run
 	// sky: skyw*skyh texels + skyw+1 zero guard texels, 3 floats each
@@ -97,6 +98,7 @@ struct WbrtBvh
 	int depth = 0;
 };
 void wbrt_build_bvh(const float4 *tri_geom, const int2 *ranges, int B, bool split_by_e, WbrtBvh &bvh);
+void wbrt_append_sphere_tree(const float4 *sph_geom, const float *radius, int S, WbrtBvh &bvh);
 
 hipError_t wbrt_launch_render(const RenderParams &p, hipStream_t stream);
 hipError_t wbrt_launch_count(const RenderParams &p, hipStream_t stream);

@@ -590,6 +590,8 @@ struct BvhRay
 	float4 o;
 	F3 d, inv;
 	float rc, dlen, padc, slop, e_limit, rho_pad;
+	float a;        // dot(d, d), as the sphere test computes it
+	bool spheres;   // the hierarchy being walked is the one over the spheres
 };
 
 __device__ __forceinline__ void bvh_load_ray(const StealLds &w, int slot, BvhRay &r)
@@ -598,7 +600,9 @@ __device__ __forceinline__ void bvh_load_ray(const StealLds &w, int slot, BvhRay
 	r.d = f3(w.ray[3][slot], w.ray[4][slot], w.ray[5][slot]);
 	r.rc = w.ray[6][slot];
 	r.inv = f3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
-	r.dlen = sqrtf(dot(r.d, r.d)) * 1.000001f;
+	r.a = dot(r.d, r.d);
+	r.dlen = sqrtf(r.a) * 1.000001f;
+	r.spheres = false;
 }
 
 // margins of ray r against the hierarchy of `box`; returns its root reference (INT_MIN: no triangles)
@@ -611,14 +615,23 @@ __device__ __forceinline__ int bvh_enter_box(const SceneDev &sc, int box, BvhRay
 	                  fmaxf(fabsf(r.o.z - r0.z), fabsf(r.o.z - r1.z));
 	const float diag = (r1.x - r0.x) + (r1.y - r0.y) + (r1.z - r0.z);
 	const float R = (far + diag) * 1.000001f;
-	r.padc = 0.35f * R * r.dlen;
 	r.slop = 1e-6f * (R + fabsf(r.o.x) + fabsf(r.o.y) + fabsf(r.o.z));
+	r.spheres = sc.sph_tree && box == sc.B;
+	if (r.spheres)
+	{
+		// box margins of this hierarchy are computed per child from the child's own box
+		r.padc = 0.0f;
+		r.rho_pad = 0.0f;
+		r.e_limit = INFINITY;
+		return __float_as_int(r0.w);
+	}
+	r.padc = 0.35f * R * r.dlen;
 	r.e_limit = 6.0f / r.dlen;
 	r.rho_pad = sc.bvh_rho * R + r.slop;
 	return r1.w < 0.0f ? BVH_NONE : __float_as_int(r0.w);
 }
 
-__device__ __forceinline__ void triangles_steal(const SceneDev &sc, int (*stack)[256], StealLds &w, bool trace,
+__device__ __forceinline__ void triangles_steal(const SceneDev &sc, int (*stack)[256], StealLds &w, bool trace, bool spheres,
                                                 F3 o, F3 d, float &closest, int &id)
 {
 	const float tmin = 0.001f;
@@ -637,6 +650,9 @@ __device__ __forceinline__ void triangles_steal(const SceneDev &sc, int (*stack)
 	// boxes queues the rest in a further pass.
 	int start = 0; // first box this lane has not queued yet
 	int node = BVH_NONE, sp = 0, bot = 0, cur = col, cur_box = 0;
+	// the sphere hierarchy (if the lane's ray walks it) is queued first: it is the largest job,
+	// and thieves take the oldest entry
+	if (spheres) stack[sp++][col] = BVH_BOX_TAG | sc.B;
 	for (;;)
 	{
 		int resume = sc.B;
@@ -721,7 +737,18 @@ __device__ __forceinline__ void triangles_steal(const SceneDev &sc, int (*stack)
 				const float best = __uint_as_float((unsigned)(w.best[cur] >> 32));
 				float pad_l = q3.z <= r.e_limit ? q3.z * r.padc + r.slop : INFINITY;
 				float pad_r = q3.w <= r.e_limit ? q3.w * r.padc + r.slop : INFINITY;
-				if (sc.bvh_rho > 0.0f)
+				if (r.spheres)
+				{
+					// 2e-3 * (|o - center| + radius) for every sphere below the child: the 1-norm distance
+					// from the origin to the far corner of the child's box bounds that sum
+					const float far_l = fmaxf(fabsf(q0.x - r.o.x), fabsf(q0.w - r.o.x)) + fmaxf(fabsf(q0.y - r.o.y), fabsf(q1.x - r.o.y)) +
+					                    fmaxf(fabsf(q0.z - r.o.z), fabsf(q1.y - r.o.z));
+					const float far_r = fmaxf(fabsf(q1.z - r.o.x), fabsf(q2.y - r.o.x)) + fmaxf(fabsf(q1.w - r.o.y), fabsf(q2.z - r.o.y)) +
+					                    fmaxf(fabsf(q2.x - r.o.z), fabsf(q2.w - r.o.z));
+					pad_l = 2.001e-3f * far_l + r.slop;
+					pad_r = 2.001e-3f * far_r + r.slop;
+				}
+				else if (sc.bvh_rho > 0.0f)
 				{
 					pad_l = fminf(pad_l, r.rho_pad);
 					pad_r = fminf(pad_r, r.rho_pad);
@@ -741,10 +768,30 @@ __device__ __forceinline__ void triangles_steal(const SceneDev &sc, int (*stack)
 				const int first = leaf >> 4, more = leaf & 15;
 				node = more ? ~(((first + 1) << 4) | (more - 1)) : BVH_NONE;
 				const float4 g0 = sc.bvh_tris[3 * (size_t)first];
-				const float4 g1 = sc.bvh_tris[3 * (size_t)first + 1];
 				const float4 g2 = sc.bvh_tris[3 * (size_t)first + 2];
-				const F3 p0 = f3(g0.x, g0.y, g0.z), e0 = f3(g0.w, g1.x, g1.y), e1 = f3(g1.z, g1.w, g2.x);
 				const F3 ro = f3(r.o.x, r.o.y, r.o.z);
+				if (r.spheres)
+				{
+					// gpu_kernel.cl:455-478 with tMax = +inf: the nearest root at or beyond tMin; the
+					// atomic min on (root, S - 1 - index) then keeps what the sequential loop with its
+					// shrinking, inclusive tMax keeps (the later sphere on a tie)
+					F3 oc = ro - f3(g0.x, g0.y, g0.z);
+					float hb = dot(oc, r.d);
+					float cc = dot(oc, oc) - g0.w;
+					float disc = hb * hb - r.a * cc;
+					if (disc < 0) continue;
+					float sq = sqrtf(disc);
+					float root = (-hb - sq) / r.a;
+					if (root < tmin)
+					{
+						root = (-hb + sq) / r.a;
+						if (root < tmin) continue;
+					}
+					atomicMin(&w.best[cur], ((unsigned long long)__float_as_uint(root) << 32) | (unsigned)(sc.S - 1 - __float_as_int(g2.y)));
+					continue;
+				}
+				const float4 g1 = sc.bvh_tris[3 * (size_t)first + 1];
+				const F3 p0 = f3(g0.x, g0.y, g0.z), e0 = f3(g0.w, g1.x, g1.y), e1 = f3(g1.z, g1.w, g2.x);
 				F3 h = cross(r.d, e1);
 				float det = dot(e0, h);
 				if (det > -0.00001f && det < 0.00001f) continue;
@@ -757,7 +804,7 @@ __device__ __forceinline__ void triangles_steal(const SceneDev &sc, int (*stack)
 				if (v < 0.0f || u + v > 1.0f) continue;
 				float t0 = f * dot(e1, q);
 				if (t0 > tmin && t0 < r.rc)
-					atomicMin(&w.best[cur], ((unsigned long long)__float_as_uint(t0) << 32) | (unsigned)__float_as_int(g2.y));
+					atomicMin(&w.best[cur], ((unsigned long long)__float_as_uint(t0) << 32) | (unsigned)(sc.S + __float_as_int(g2.y)));
 			}
 		}
 		// every stack is empty again; lanes that could not queue all their boxes go round once more
@@ -770,8 +817,10 @@ __device__ __forceinline__ void triangles_steal(const SceneDev &sc, int (*stack)
 	const unsigned long long k = w.best[col];
 	if (trace && (unsigned)k != 0xFFFFFFFFu)
 	{
+		// low word: S - 1 - sphere index, or S + position of the triangle in the grouped order
+		const int low = (int)(unsigned)k;
 		closest = __uint_as_float((unsigned)(k >> 32));
-		id = sc.S + (int)(unsigned)k;
+		id = low < sc.S ? sc.S - 1 - low : low;
 	}
 }
 
@@ -932,7 +981,7 @@ __global__ __launch_bounds__(256) void k_render(const RenderParams p)
 		// 0 = path continues, 1 = ended black, 2 = ended on the sky, 3 = ended with `col`
 		int outcome = 0;
 		F3 col = f3(0.0f, 0.0f, 0.0f);
-		bool trace = false;
+		bool trace = false, walk_spheres = false;
 		float t = INFINITY;
 		int id = -1;
 		if (!MESH || alive)
@@ -947,7 +996,15 @@ __global__ __launch_bounds__(256) void k_render(const RenderParams p)
 			{
 				trace = true;
 				if (STATS) ctr.add(C_SEGMENTS, 1);
-				closest_sphere<STATS>(sc, L.o, L.d, t, id, ctr);
+				// Many spheres: the ray walks the sphere hierarchy together with the triangle
+				// hierarchies below, unless its numbers are outside the range the margins of
+				// that walk were derived for (then the loop over all spheres runs here).
+				if (MESH && !STATS && sc.sph_tree && sc.bvh_nodes)
+				{
+					const float a = dot(L.d, L.d);
+					walk_spheres = a > 1e-20f && a < 1e4f && fabsf(L.o.x) < 1e8f && fabsf(L.o.y) < 1e8f && fabsf(L.o.z) < 1e8f;
+				}
+				if (!walk_spheres) closest_sphere<STATS>(sc, L.o, L.d, t, id, ctr);
 			}
 		}
 		if (MESH)
@@ -956,7 +1013,7 @@ __global__ __launch_bounds__(256) void k_render(const RenderParams p)
 			{
 				if (trace) boxes_and_triangles<STATS>(sc, s_tiles[threadIdx.x >> 6], L.o, L.d, t, id, ctr);
 			}
-			else if (sc.bvh_nodes) triangles_steal(sc, s_stack, s_steal[0], trace, L.o, L.d, t, id);
+			else if (sc.bvh_nodes) triangles_steal(sc, s_stack, s_steal[0], trace, walk_spheres, L.o, L.d, t, id);
 			else triangles_cooperative(sc, s_best[threadIdx.x >> 6], trace, L.o, L.d, t, id);
 		}
 		if (MESH && !alive) continue;
@@ -1253,7 +1310,7 @@ inline unsigned grid_for(const RenderParams &p)
 
 hipError_t wbrt_launch_render(const RenderParams &p, hipStream_t stream)
 {
-	if (p.sc.B > 0) hipLaunchKernelGGL((k_render<false, true>), dim3(grid_for(p)), dim3(256), 0, stream, p);
+	if (p.sc.B > 0 || (p.sc.sph_tree && p.sc.bvh_nodes)) hipLaunchKernelGGL((k_render<false, true>), dim3(grid_for(p)), dim3(256), 0, stream, p);
 	else
 	{
 		// one wave per workgroup: no LDS here, and single waves fill freed slots soonest

@@ -235,6 +235,47 @@ def test_mesh_goldens_at_size(gpu_ctx):
     assert np.array_equal(gpu_ctx.primary_ids(cam), full["ids"].astype(np.int32))
 
 
+@pytest.mark.parametrize("case", [("spheres", 300, 160, 4), ("spheres+mesh", 200, 128, 3), ("hollow", 160, 128, 4)])
+def test_many_spheres_walk_equals_loop_and_oracle(gpu_ctx, case):
+    """From 128 spheres on the render build walks a hierarchy over the spheres; it must keep
+    the sequential loop's winner (nearest accepted root, the later sphere on a tie)."""
+    name, n_spheres, width, spp = case
+    full = pkg.scene_stress(n_spheres, 24, 24, 4, 4)
+    if name == "spheres":
+        scene = pkg.Scene(spheres=full.spheres)
+    elif name == "hollow":
+        # duplicates (tie: the later one wins), hollow glass (negative radius) and concentric shells
+        s = (pkg.Sphere * (n_spheres + 24))()
+        for i in range(n_spheres):
+            s[i] = full.spheres[i]
+        for k in range(8):
+            src = full.spheres[1 + k]
+            s[n_spheres + 3 * k] = pkg.Sphere(src.center, src.radius, pkg.material((0.9, 0.2, 0.2), 0.0, 0.0, pkg.EMISSIVE))
+            s[n_spheres + 3 * k + 1] = pkg.Sphere(full.spheres[20 + k].center, full.spheres[20 + k].radius * 1.5,
+                                                  pkg.material((1, 1, 1), 0.0, 1.5, pkg.DIELECTRIC))
+            s[n_spheres + 3 * k + 2] = pkg.Sphere(full.spheres[20 + k].center, -full.spheres[20 + k].radius * 1.4,
+                                                  pkg.material((1, 1, 1), 0.0, 1.5, pkg.DIELECTRIC))
+        scene = pkg.Scene(spheres=s)
+    else:
+        scene = full
+    cam = pkg.camera_stress(width, spp, 50)
+    seeds = _setup(gpu_ctx, scene, cam, 4, 31)
+    try:
+        gpu_ctx.set_mesh_mode(pkg.MESH_BVH)
+        walk = gpu_ctx.render_frame(cam)
+        gpu_ctx.set_mesh_mode(pkg.MESH_BVH_STRICT)
+        strict = gpu_ctx.render_frame(cam)
+        gpu_ctx.set_mesh_mode(pkg.MESH_LOOP)
+        loop = gpu_ctx.render_frame(cam)
+    finally:
+        gpu_ctx.set_mesh_mode(pkg.MESH_BVH)
+    assert np.array_equal(bits(walk), bits(loop))
+    assert np.array_equal(bits(strict), bits(loop))
+    O = orc.Oracle(scene)
+    assert np.array_equal(bits(loop), bits(O.render_frame(cam, seeds)))
+    assert np.array_equal(gpu_ctx.primary_ids(cam), O.primary_ids(cam, seeds))
+
+
 def test_block_entry_point_equals_frame_region(gpu_ctx):
     scene, cam = pkg.scene_readme(), pkg.camera_readme(160, 4, 50)
     _setup(gpu_ctx, scene, cam, 4, 12)
