@@ -77,7 +77,7 @@ struct wbrt_context
 	int pilot_spp = 4;
 	SceneDev sc{};
 	bool have_scene = false, have_sky = false, have_bvh = false, have_sphere_tree = false;
-	int sphere_tree_min = 128; // sphere count from which the render build walks a sphere hierarchy
+	int sphere_tree_min = 48;  // sphere count from which the render build walks a sphere hierarchy
 	size_t n_seeds = 0;
 	bool timing = false;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> events;

@@ -237,7 +237,7 @@ def test_mesh_goldens_at_size(gpu_ctx):
 
 @pytest.mark.parametrize("case", [("spheres", 300, 160, 4), ("spheres+mesh", 200, 128, 3), ("hollow", 160, 128, 4)])
 def test_many_spheres_walk_equals_loop_and_oracle(gpu_ctx, case):
-    """From 128 spheres on the render build walks a hierarchy over the spheres; it must keep
+    """From 48 spheres on the render build walks a hierarchy over the spheres; it must keep
     the sequential loop's winner (nearest accepted root, the later sphere on a tie)."""
     name, n_spheres, width, spp = case
     full = pkg.scene_stress(n_spheres, 24, 24, 4, 4)
