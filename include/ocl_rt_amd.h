@@ -141,7 +141,11 @@ int wbrt_synchronize(wbrt_context *ctx);
  *                         within about one degree of a triangle's plane that passes that
  *                         triangle at more than the margin: there the reference's own
  *                         accept/reject decision is rounding noise.
- * Primary ids and event counters always use the loop.  Takes effect at the next render. */
+ * In both BVH modes scenes with 48 or more spheres also walk a hierarchy over the spheres
+ * (margins proven from the reference's float sphere test: same result as its loop over all
+ * spheres, gpu_kernel.cl:361-371); WBRT_MESH_LOOP loops over all spheres as well.  In strict
+ * mode meshes of at most 4096 triangles use the loop.
+ * Primary ids and event counters always use the loops.  Takes effect at the next render. */
 enum { WBRT_MESH_LOOP = 0, WBRT_MESH_BVH_STRICT = 1, WBRT_MESH_BVH = 2 };
 int wbrt_set_mesh_mode(wbrt_context *ctx, int mode);
 
