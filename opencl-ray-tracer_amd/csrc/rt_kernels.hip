@@ -599,9 +599,11 @@ __device__ __forceinline__ void bvh_load_ray(const StealLds &w, int slot, BvhRay
 	r.o = make_float4(w.ray[0][slot], w.ray[1][slot], w.ray[2][slot], 0.0f);
 	r.d = f3(w.ray[3][slot], w.ray[4][slot], w.ray[5][slot]);
 	r.rc = w.ray[6][slot];
-	r.inv = f3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+	// the walk's own box tests tolerate the 1-ulp hardware reciprocal and square root (their
+	// error is far inside the box margins); the reference's slab test does not use these
+	r.inv = f3(__builtin_amdgcn_rcpf(r.d.x), __builtin_amdgcn_rcpf(r.d.y), __builtin_amdgcn_rcpf(r.d.z));
 	r.a = dot(r.d, r.d);
-	r.dlen = sqrtf(r.a) * 1.000001f;
+	r.dlen = __builtin_amdgcn_sqrtf(r.a) * 1.00001f;
 	r.spheres = false;
 }
 
@@ -626,7 +628,7 @@ __device__ __forceinline__ int bvh_enter_box(const SceneDev &sc, int box, BvhRay
 		return __float_as_int(r0.w);
 	}
 	r.padc = 0.35f * R * r.dlen;
-	r.e_limit = 6.0f / r.dlen;
+	r.e_limit = 5.99f * __builtin_amdgcn_rcpf(r.dlen);
 	r.rho_pad = sc.bvh_rho * R + r.slop;
 	return r1.w < 0.0f ? BVH_NONE : __float_as_int(r0.w);
 }
@@ -643,6 +645,7 @@ __device__ __forceinline__ void triangles_steal(const SceneDev &sc, int (*stack)
 	__builtin_amdgcn_wave_barrier();
 	BvhRay r;
 	bvh_load_ray(w, col, r);
+	const F3 inv_d = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); // gpu_kernel.cl:536: the reference's invDirection
 	const unsigned long long below = (1ull << lane) - 1ull;
 	// Boxes whose slab test passes for the lane's own ray are queued on the lane's stack as
 	// BVH_BOX_TAG | box; an entry turns into that box's root when a worker takes it.  A stack
@@ -659,12 +662,12 @@ __device__ __forceinline__ void triangles_steal(const SceneDev &sc, int (*stack)
 		for (int b = 0; b < sc.B; ++b)
 		{
 			const float4 mn = uniform_ld(sc.box_min, b), mx = uniform_ld(sc.box_max, b);
-			float tx1 = (mn.x - o.x) * r.inv.x, tx2 = (mx.x - o.x) * r.inv.x;
+			float tx1 = (mn.x - o.x) * inv_d.x, tx2 = (mx.x - o.x) * inv_d.x;
 			float lo = fminf(tx1, tx2), hi = fmaxf(tx1, tx2);
-			float ty1 = (mn.y - o.y) * r.inv.y, ty2 = (mx.y - o.y) * r.inv.y;
+			float ty1 = (mn.y - o.y) * inv_d.y, ty2 = (mx.y - o.y) * inv_d.y;
 			lo = fmaxf(lo, fminf(ty1, ty2));
 			hi = fminf(hi, fmaxf(ty1, ty2));
-			float tz1 = (mn.z - o.z) * r.inv.z, tz2 = (mx.z - o.z) * r.inv.z;
+			float tz1 = (mn.z - o.z) * inv_d.z, tz2 = (mx.z - o.z) * inv_d.z;
 			lo = fmaxf(lo, fminf(tz1, tz2));
 			hi = fminf(hi, fmaxf(tz1, tz2));
 			if (trace && b >= start && hi > fmaxf(lo, 0.0f))
