@@ -556,12 +556,13 @@ __device__ __forceinline__ void triangles_cooperative(const SceneDev &sc, unsign
 // on how far outside its triangle the float test can still accept a hit, so skipping a node
 // never drops a triangle the reference would have accepted.
 
-__device__ __forceinline__ bool bvh_box(float4 ray_o, F3 inv, float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
-                                        float pad, float best, float &lo)
+// o_near = o + margin, o_far = o - margin: the box [mn - margin, mx + margin] seen from o
+__device__ __forceinline__ bool bvh_box(F3 o_near, F3 o_far, F3 inv, float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
+                                        float best, float &lo)
 {
-	const float tx1 = (mnx - pad - ray_o.x) * inv.x, tx2 = (mxx + pad - ray_o.x) * inv.x;
-	const float ty1 = (mny - pad - ray_o.y) * inv.y, ty2 = (mxy + pad - ray_o.y) * inv.y;
-	const float tz1 = (mnz - pad - ray_o.z) * inv.z, tz2 = (mxz + pad - ray_o.z) * inv.z;
+	const float tx1 = (mnx - o_near.x) * inv.x, tx2 = (mxx - o_far.x) * inv.x;
+	const float ty1 = (mny - o_near.y) * inv.y, ty2 = (mxy - o_far.y) * inv.y;
+	const float tz1 = (mnz - o_near.z) * inv.z, tz2 = (mxz - o_far.z) * inv.z;
 	lo = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), fminf(tz1, tz2));
 	const float hi = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fmaxf(tz1, tz2));
 	// written so that a NaN anywhere means "visit"
@@ -590,6 +591,7 @@ struct BvhRay
 	float4 o;
 	F3 d, inv;
 	float rc, dlen, padc, slop, e_limit, rho_pad;
+	F3 o_near, o_far; // o +- rho_pad: capped-margin mode, one margin per ray and box
 	float a;        // dot(d, d), as the sphere test computes it
 	bool spheres;   // the hierarchy being walked is the one over the spheres
 };
@@ -630,6 +632,8 @@ __device__ __forceinline__ int bvh_enter_box(const SceneDev &sc, int box, BvhRay
 	r.padc = 0.35f * R * r.dlen;
 	r.e_limit = 5.99f * __builtin_amdgcn_rcpf(r.dlen);
 	r.rho_pad = sc.bvh_rho * R + r.slop;
+	r.o_near = f3(r.o.x + r.rho_pad, r.o.y + r.rho_pad, r.o.z + r.rho_pad);
+	r.o_far = f3(r.o.x - r.rho_pad, r.o.y - r.rho_pad, r.o.z - r.rho_pad);
 	return r1.w < 0.0f ? BVH_NONE : __float_as_int(r0.w);
 }
 
@@ -738,27 +742,38 @@ __device__ __forceinline__ void triangles_steal(const SceneDev &sc, int (*stack)
 				const float4 q0 = sc.bvh_nodes[4 * (size_t)node], q1 = sc.bvh_nodes[4 * (size_t)node + 1];
 				const float4 q2 = sc.bvh_nodes[4 * (size_t)node + 2], q3 = sc.bvh_nodes[4 * (size_t)node + 3];
 				const float best = __uint_as_float((unsigned)(w.best[cur] >> 32));
-				float pad_l = q3.z <= r.e_limit ? q3.z * r.padc + r.slop : INFINITY;
-				float pad_r = q3.w <= r.e_limit ? q3.w * r.padc + r.slop : INFINITY;
-				if (r.spheres)
-				{
-					// 2e-3 * (|o - center| + radius) for every sphere below the child: the 1-norm distance
-					// from the origin to the far corner of the child's box bounds that sum
-					const float far_l = fmaxf(fabsf(q0.x - r.o.x), fabsf(q0.w - r.o.x)) + fmaxf(fabsf(q0.y - r.o.y), fabsf(q1.x - r.o.y)) +
-					                    fmaxf(fabsf(q0.z - r.o.z), fabsf(q1.y - r.o.z));
-					const float far_r = fmaxf(fabsf(q1.z - r.o.x), fabsf(q2.y - r.o.x)) + fmaxf(fabsf(q1.w - r.o.y), fabsf(q2.z - r.o.y)) +
-					                    fmaxf(fabsf(q2.x - r.o.z), fabsf(q2.w - r.o.z));
-					pad_l = 2.001e-3f * far_l + r.slop;
-					pad_r = 2.001e-3f * far_r + r.slop;
-				}
-				else if (sc.bvh_rho > 0.0f)
-				{
-					pad_l = fminf(pad_l, r.rho_pad);
-					pad_r = fminf(pad_r, r.rho_pad);
-				}
 				float lo_l, lo_r;
-				const bool vl = bvh_box(r.o, r.inv, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, pad_l, best, lo_l);
-				const bool vr = bvh_box(r.o, r.inv, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, pad_r, best, lo_r);
+				bool vl, vr;
+				if (!r.spheres && sc.bvh_rho > 0.0f)
+				{
+					// capped margins: one number per ray and box (never below min(strict margin, cap))
+					vl = bvh_box(r.o_near, r.o_far, r.inv, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, best, lo_l);
+					vr = bvh_box(r.o_near, r.o_far, r.inv, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, best, lo_r);
+				}
+				else
+				{
+					float pad_l, pad_r;
+					if (r.spheres)
+					{
+						// 2e-3 * (|o - center| + radius) for every sphere below the child: the 1-norm distance
+						// from the origin to the far corner of the child's box bounds that sum
+						const float far_l = fmaxf(fabsf(q0.x - r.o.x), fabsf(q0.w - r.o.x)) + fmaxf(fabsf(q0.y - r.o.y), fabsf(q1.x - r.o.y)) +
+						                    fmaxf(fabsf(q0.z - r.o.z), fabsf(q1.y - r.o.z));
+						const float far_r = fmaxf(fabsf(q1.z - r.o.x), fabsf(q2.y - r.o.x)) + fmaxf(fabsf(q1.w - r.o.y), fabsf(q2.z - r.o.y)) +
+						                    fmaxf(fabsf(q2.x - r.o.z), fabsf(q2.w - r.o.z));
+						pad_l = 2.001e-3f * far_l + r.slop;
+						pad_r = 2.001e-3f * far_r + r.slop;
+					}
+					else
+					{
+						pad_l = q3.z <= r.e_limit ? q3.z * r.padc + r.slop : INFINITY;
+						pad_r = q3.w <= r.e_limit ? q3.w * r.padc + r.slop : INFINITY;
+					}
+					vl = bvh_box(f3(r.o.x + pad_l, r.o.y + pad_l, r.o.z + pad_l), f3(r.o.x - pad_l, r.o.y - pad_l, r.o.z - pad_l), r.inv,
+					             q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, best, lo_l);
+					vr = bvh_box(f3(r.o.x + pad_r, r.o.y + pad_r, r.o.z + pad_r), f3(r.o.x - pad_r, r.o.y - pad_r, r.o.z - pad_r), r.inv,
+					             q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, best, lo_r);
+				}
 				const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
 				const bool left_first = !(lo_r < lo_l);
 				if (vl & vr) stack[sp++][col] = left_first ? right : left;
