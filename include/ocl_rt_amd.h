@@ -182,6 +182,9 @@ void wbrt_tonemap_host(const float *image, float scale, int32_t width, int32_t h
 /* headless writers replacing the Win32 window + output.bmp (main.cpp:262-265) */
 int wbrt_write_ppm(const char *path, const uint8_t *rgb8, int32_t width, int32_t height);
 int wbrt_write_pfm(const char *path, const float *image, int32_t width, int32_t height);
+/* linear float picture as an uncompressed OpenEXR scanline file (channels B,G,R float32);
+ * image: width*height texels, row 0 = bottom, as the render entry points deliver it */
+int wbrt_write_exr(const char *path, const float *image, int32_t width, int32_t height);
 /* generateBitmapImage (bitmap_io.cpp:3-29): 24-bit bottom-up BMP from top-down RGB8 */
 int wbrt_write_bmp(const char *path, const uint8_t *rgb8, int32_t width, int32_t height);
 

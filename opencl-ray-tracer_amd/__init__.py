@@ -119,6 +119,7 @@ _SIGNATURES = {
     "wbrt_write_ppm": (C.c_int, [C.c_char_p, _P, C.c_int32, C.c_int32]),
     "wbrt_write_pfm": (C.c_int, [C.c_char_p, _P, C.c_int32, C.c_int32]),
     "wbrt_write_bmp": (C.c_int, [C.c_char_p, _P, C.c_int32, C.c_int32]),
+    "wbrt_write_exr": (C.c_int, [C.c_char_p, _P, C.c_int32, C.c_int32]),
     "wbrt_read_mesh": (C.c_int, [C.c_char_p, Vec3, Vec3, Material, C.c_int32, _P, C.POINTER(C.c_int32),
                                  C.POINTER(C.c_int32), C.POINTER(Vec3), C.POINTER(Vec3)]),
     "wbrt_sky_tonemap": (None, [_P, C.c_size_t, _P]),
@@ -248,6 +249,11 @@ def write_ppm(path, rgb8):
 def write_pfm(path, image):
     h, w, _ = image.shape
     _check(lib().wbrt_write_pfm(path.encode(), _ptr(np.ascontiguousarray(image, dtype=np.float32)), w, h))
+
+
+def write_exr(path, image):
+    h, w, _ = image.shape
+    _check(lib().wbrt_write_exr(path.encode(), _ptr(np.ascontiguousarray(image, dtype=np.float32)), w, h))
 
 
 def write_bmp(path, rgb8):

@@ -186,6 +186,62 @@ int wbrt_write_pfm(const char *path, const float *image, int32_t width, int32_t 
 	return WBRT_OK;
 }
 
+// OpenEXR 2 scanline file, no compression, three 32-bit float channels (B, G, R: the format
+// orders channels by name), increasing-y line order with row 0 of the file = TOP of the picture
+// (the render's rows are bottom-to-top, so they are written in reverse).  Linear values, no
+// tone map: the headless float output next to the 8-bit PPM/BMP.
+int wbrt_write_exr(const char *path, const float *image, int32_t width, int32_t height)
+{
+	if (!image || width <= 0 || height <= 0) { g_error = "bad image"; return WBRT_ERR_INVALID; }
+	std::vector<unsigned char> head;
+	auto put = [&](const void *p, size_t n) { const unsigned char *b = (const unsigned char *)p; head.insert(head.end(), b, b + n); };
+	auto put_str = [&](const char *z) { put(z, std::strlen(z) + 1); };
+	auto put_i32 = [&](int32_t v) { put(&v, 4); };
+	auto put_f32 = [&](float v) { put(&v, 4); };
+	auto attr = [&](const char *name, const char *type, int32_t size) { put_str(name); put_str(type); put_i32(size); };
+	const uint32_t magic = 20000630u, version = 2u;
+	put(&magic, 4); put(&version, 4);
+	attr("channels", "chlist", 3 * 18 + 1);
+	for (const char *c : { "B", "G", "R" })
+	{
+		put_str(c);            // name
+		put_i32(2);            // pixel type FLOAT
+		put_i32(0);            // pLinear + 3 reserved bytes
+		put_i32(1); put_i32(1); // x, y sampling
+	}
+	head.push_back(0);
+	attr("compression", "compression", 1); head.push_back(0);
+	attr("dataWindow", "box2i", 16); put_i32(0); put_i32(0); put_i32(width - 1); put_i32(height - 1);
+	attr("displayWindow", "box2i", 16); put_i32(0); put_i32(0); put_i32(width - 1); put_i32(height - 1);
+	attr("lineOrder", "lineOrder", 1); head.push_back(0);
+	attr("pixelAspectRatio", "float", 4); put_f32(1.0f);
+	attr("screenWindowCenter", "v2f", 8); put_f32(0.0f); put_f32(0.0f);
+	attr("screenWindowWidth", "float", 4); put_f32(1.0f);
+	head.push_back(0); // end of header
+	const uint64_t line_bytes = 8 + (uint64_t)width * 12;
+	const uint64_t first = head.size() + (uint64_t)height * 8;
+	for (int32_t y = 0; y < height; ++y) { uint64_t off = first + (uint64_t)y * line_bytes; put(&off, 8); }
+	FILE *f = std::fopen(path, "wb");
+	if (!f) { g_error = std::string("cannot open ") + path; return WBRT_ERR_IO; }
+	bool ok = std::fwrite(head.data(), 1, head.size(), f) == head.size();
+	std::vector<float> line((size_t)width * 3);
+	for (int32_t y = 0; y < height && ok; ++y)
+	{
+		const float *src = image + (size_t)(height - 1 - y) * width * 3;
+		for (int32_t x = 0; x < width; ++x)
+		{
+			line[(size_t)x] = src[3 * x + 2];
+			line[(size_t)width + x] = src[3 * x + 1];
+			line[(size_t)2 * width + x] = src[3 * x + 0];
+		}
+		const int32_t hdr[2] = { y, width * 12 };
+		ok = std::fwrite(hdr, 4, 2, f) == 2 && std::fwrite(line.data(), 4, line.size(), f) == line.size();
+	}
+	std::fclose(f);
+	if (!ok) { g_error = std::string("short write ") + path; return WBRT_ERR_IO; }
+	return WBRT_OK;
+}
+
 // bitmap_io.cpp:3-84: 14-byte file header + 40-byte info header (only size, width, height,
 // planes = 1 and bpp = 24 are filled), rows bottom-up, B,G,R, padded to 4 bytes.
 int wbrt_write_bmp(const char *path, const uint8_t *rgb8, int32_t width, int32_t height)

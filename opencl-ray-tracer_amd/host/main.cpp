@@ -173,6 +173,7 @@ int main(int argc, char **argv)
 	            (double)W * H * cfg.samples_per_pixel / secs / 1e6);
 	CHECK(wbrt_write_ppm((out + ".ppm").c_str(), rgb8.data(), W, H));
 	CHECK(wbrt_write_pfm((out + ".pfm").c_str(), image.data(), W, H));
+	CHECK(wbrt_write_exr((out + ".exr").c_str(), (const float *)image.data(), W, H));
 	CHECK(wbrt_write_bmp((out + ".bmp").c_str(), rgb8.data(), W, H));
 	wbrt_destroy(ctx);
 	return 0;

@@ -53,3 +53,4 @@ def test_driver_output_equals_library_calls(gpu_ctx, tmp_path, mode):
     assert ppm.startswith(b"P6\n256 144\n255\n")
     assert ppm[len(b"P6\n256 144\n255\n"):] == pkg.tonemap_host(want).tobytes()
     assert os.path.getsize(out + ".bmp") == 54 + 256 * 144 * 3
+    assert os.path.getsize(out + ".exr") > 256 * 144 * 12

@@ -228,3 +228,43 @@ def test_write_colour_and_bmp_match_reference(tmp_path):
     p = tmp_path / "t.bmp"
     pkg.write_bmp(str(p), np.ascontiguousarray(rgb_top_down))
     assert p.read_bytes() == z["bmp_file"].tobytes()
+
+
+def test_exr_writer_round_trip(tmp_path):
+    """Uncompressed OpenEXR scanline file: parsed back here by the published layout (magic,
+    version, attribute list, offset table, per-line y + size + channel-planar B,G,R floats)."""
+    import struct
+    rs = np.random.RandomState(3)
+    h, w = 5, 7
+    img = rs.uniform(0, 4, (h, w, 3)).astype(np.float32)  # row 0 = bottom
+    path = str(tmp_path / "x.exr")
+    pkg.write_exr(path, img)
+    b = open(path, "rb").read()
+    assert struct.unpack_from("<II", b, 0) == (20000630, 2)
+    pos, attrs = 8, {}
+    while b[pos] != 0:
+        e = b.index(b"\0", pos); name = b[pos:e].decode(); pos = e + 1
+        e = b.index(b"\0", pos); typ = b[pos:e].decode(); pos = e + 1
+        (size,) = struct.unpack_from("<i", b, pos); pos += 4
+        attrs[name] = (typ, b[pos:pos + size]); pos += size
+    pos += 1
+    assert set(attrs) >= {"channels", "compression", "dataWindow", "displayWindow", "lineOrder", "pixelAspectRatio",
+                          "screenWindowCenter", "screenWindowWidth"}
+    assert attrs["compression"] == ("compression", b"\0") and attrs["lineOrder"] == ("lineOrder", b"\0")
+    assert struct.unpack("<4i", attrs["dataWindow"][1]) == (0, 0, w - 1, h - 1)
+    ch, names = attrs["channels"][1], []
+    q = 0
+    while ch[q] != 0:
+        e = ch.index(b"\0", q); names.append(ch[q:e].decode()); q = e + 1
+        assert struct.unpack_from("<i", ch, q)[0] == 2 and struct.unpack_from("<ii", ch, q + 8) == (1, 1)
+        q += 16
+    assert names == ["B", "G", "R"]
+    offsets = struct.unpack_from("<%dQ" % h, b, pos)
+    out = np.zeros((h, w, 3), np.float32)
+    for y, off in enumerate(offsets):
+        yy, size = struct.unpack_from("<ii", b, off)
+        assert (yy, size) == (y, w * 12)
+        planes = np.frombuffer(b, dtype="<f4", count=3 * w, offset=off + 8).reshape(3, w)
+        out[h - 1 - y, :, 2], out[h - 1 - y, :, 1], out[h - 1 - y, :, 0] = planes[0], planes[1], planes[2]
+    assert offsets[-1] + 8 + w * 12 == len(b)
+    assert np.array_equal(out.view(np.uint32), img.view(np.uint32))
