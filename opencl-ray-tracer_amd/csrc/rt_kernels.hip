@@ -638,7 +638,7 @@ __device__ __forceinline__ int bvh_enter_box(const SceneDev &sc, int box, BvhRay
 }
 
 __device__ __forceinline__ void triangles_steal(const SceneDev &sc, int (*stack)[256], StealLds &w, bool trace, bool spheres,
-                                                F3 o, F3 d, float &closest, int &id)
+                                                F3 o, F3 d, float &closest, int &id, int &rounds)
 {
 	const float tmin = 0.001f;
 	const int col = threadIdx.x, base = threadIdx.x & ~63, lane = threadIdx.x & 63;
@@ -736,6 +736,7 @@ __device__ __forceinline__ void triangles_steal(const SceneDev &sc, int (*stack)
 				}
 				__builtin_amdgcn_wave_barrier();
 			}
+			++rounds;
 			if (node == BVH_NONE) continue;
 			if (node >= 0)
 			{
@@ -992,7 +993,7 @@ __global__ __launch_bounds__(256) void k_render(const RenderParams p)
 		if (alive) camera_ray<STATS>(p, L, ctr);
 	}
 
-	int iterations = 0;
+	int iterations = 0, walk_cost = 0;
 	for (;;)
 	{
 		if (MESH ? !__ballot(alive) : !alive) break;
@@ -1031,7 +1032,14 @@ __global__ __launch_bounds__(256) void k_render(const RenderParams p)
 			{
 				if (trace) boxes_and_triangles<STATS>(sc, s_tiles[threadIdx.x >> 6], L.o, L.d, t, id, ctr);
 			}
-			else if (sc.bvh_nodes) triangles_steal(sc, s_stack, s_steal[0], trace, walk_spheres, L.o, L.d, t, id);
+			else if (sc.bvh_nodes)
+			{
+				// pilot launch: rounds of the walk join the tile's cost estimate (the sum over its
+				// lanes, so booked on one lane); weight 3 per round measured best (1..32 tried)
+				int rounds = 0;
+				triangles_steal(sc, s_stack, s_steal[0], trace, walk_spheres, L.o, L.d, t, id, rounds);
+				if (p.costs && (threadIdx.x & 63) == 0) walk_cost += 3 * rounds;
+			}
 			else triangles_cooperative(sc, s_best[threadIdx.x >> 6], trace, L.o, L.d, t, id);
 		}
 		if (MESH && !alive) continue;
@@ -1189,7 +1197,7 @@ __global__ __launch_bounds__(256) void k_render(const RenderParams p)
 	}
 	if (p.costs) // pilot launch: only the loop iterations (ray segments) of each work index
 	{
-		if (w < (long long)p.bsx * p.bsy * p.nbx * p.nby) p.costs[w] = iterations;
+		if (w < (long long)p.bsx * p.bsy * p.nbx * p.nby) p.costs[w] = iterations + walk_cost;
 		return;
 	}
 	if (w < (long long)p.bsx * p.bsy * p.nbx * p.nby)
