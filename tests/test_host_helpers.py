@@ -108,7 +108,7 @@ def test_obj_loader(tmp_path):
 
 
 def test_reference_mesh_fixture_bounds():
-    # the f1_car soup with main.cpp's transform reproduces the survey's bounding box
+    # the f1_car soup with main.cpp's transform reproduces the bounding box the reference's loader computes for it
     from util import scene_main_cpp_with_mesh
     sc = scene_main_cpp_with_mesh("f1_car")
     assert sc.T == 15329 and sc.B == 1 and sc.S == 8

@@ -28,7 +28,7 @@ def test_rng_known_answers():
             f = ol.wbo_rand_float(C.byref(st))
             assert st.value == int(states[k])
             assert np.float32(f).view(np.uint32) == floats[k].view(np.uint32)
-    # survey known answer: seed 12345 -> state 29803012144720 -> 0.10588157f
+    # known answer worked by hand from gpu_kernel.cl:173-180: seed 12345 -> state 29803012144720 -> 0.10588157f
     assert ol.wbo_next_seed(12345) == 29803012144720
     st = C.c_uint64(12345)
     assert abs(ol.wbo_rand_float(C.byref(st)) - 0.10588157) < 1e-8
