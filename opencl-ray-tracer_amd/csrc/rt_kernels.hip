@@ -579,11 +579,15 @@ __device__ __forceinline__ bool bvh_box(F3 o_near, F3 o_far, F3 inv, float mnx, 
 // "first triangle wins ties" rule whatever the order of visits; the slot's t0 also prunes
 // subtrees for every worker on that ray.  A worker's stack only ever holds nodes of ONE ray and
 // one root-to-leaf path of siblings, so its depth is bounded by the tree depth.
+// Threads per workgroup of the render kernels: one wave.  Nothing is shared between the waves of
+// a workgroup, and single waves free their LDS and fill freed slots soonest.
+#define WBRT_RENDER_BLOCK 64
+
 struct StealLds
 {
-	float ray[7][256];              // o.xyz d.xyz, sphere result (upper bound for accepted t0)
-	unsigned long long best[256];   // (t0 bits << 32) | loop position
-	int2 mail[256];                 // hand-over: node, ray slot | box << 8
+	float ray[7][WBRT_RENDER_BLOCK];              // o.xyz d.xyz, sphere result (upper bound for accepted t0)
+	unsigned long long best[WBRT_RENDER_BLOCK];   // (t0 bits << 32) | loop position
+	int2 mail[WBRT_RENDER_BLOCK];                 // hand-over: node, ray slot | box << 8
 };
 
 struct BvhRay
@@ -637,7 +641,7 @@ __device__ __forceinline__ int bvh_enter_box(const SceneDev &sc, int box, BvhRay
 	return r1.w < 0.0f ? BVH_NONE : __float_as_int(r0.w);
 }
 
-__device__ __forceinline__ void triangles_steal(const SceneDev &sc, int (*stack)[256], StealLds &w, bool trace, bool spheres,
+__device__ __forceinline__ void triangles_steal(const SceneDev &sc, int (*stack)[WBRT_RENDER_BLOCK], StealLds &w, bool trace, bool spheres,
                                                 F3 o, F3 d, float &closest, int &id, int &rounds)
 {
 	const float tmin = 0.001f;
@@ -959,11 +963,11 @@ __device__ __forceinline__ void init_lane(const RenderParams &p, Lane &L, int gi
 // done: what bounds a mesh frame is its longest pixel stream, and a lone live lane still gets
 // all 64 lanes of triangle throughput this way.
 template <bool STATS, bool MESH>
-__global__ __launch_bounds__(256) void k_render(const RenderParams p)
+__global__ __launch_bounds__(WBRT_RENDER_BLOCK) void k_render(const RenderParams p)
 {
-	__shared__ TriTiles s_tiles[MESH && STATS ? 4 : 1]; // counting build: sequential staged loop, one per wave
-	__shared__ unsigned long long s_best[MESH && !STATS ? 4 : 1][64];
-	__shared__ int s_stack[MESH && !STATS ? WBRT_BVH_STACK : 1][256]; // one column per thread
+	__shared__ TriTiles s_tiles[MESH && STATS ? WBRT_RENDER_BLOCK / 64 : 1]; // counting build: sequential staged loop, one per wave
+	__shared__ unsigned long long s_best[MESH && !STATS ? WBRT_RENDER_BLOCK / 64 : 1][64];
+	__shared__ int s_stack[MESH && !STATS ? WBRT_BVH_STACK : 1][WBRT_RENDER_BLOCK]; // one column per thread
 	__shared__ StealLds s_steal[1];
 	Counters<STATS> ctr;
 	const SceneDev &sc = p.sc;
@@ -1326,31 +1330,27 @@ __global__ void k_cost_scatter(const int *costs, int n, unsigned *offsets, int *
 		order[atomicAdd(&offsets[min(costs[i], 255)], 1u)] = i;
 }
 
-inline unsigned grid_for(const RenderParams &p)
+inline unsigned grid_for(const RenderParams &p, int block)
 {
 	long long total = (long long)p.bsx * p.bsy * p.nbx * p.nby;
-	return (unsigned)((total + 255) / 256);
+	return (unsigned)((total + block - 1) / block);
 }
 
 } // namespace
 
 hipError_t wbrt_launch_render(const RenderParams &p, hipStream_t stream)
 {
-	if (p.sc.B > 0 || (p.sc.sph_tree && p.sc.bvh_nodes)) hipLaunchKernelGGL((k_render<false, true>), dim3(grid_for(p)), dim3(256), 0, stream, p);
-	else
-	{
-		// one wave per workgroup: no LDS here, and single waves fill freed slots soonest
-		const int block = 64;
-		const long long total = (long long)p.bsx * p.bsy * p.nbx * p.nby;
-		hipLaunchKernelGGL((k_render<false, false>), dim3((unsigned)((total + block - 1) / block)), dim3(block), 0, stream, p);
-	}
+	const dim3 grid(grid_for(p, WBRT_RENDER_BLOCK)), block(WBRT_RENDER_BLOCK);
+	if (p.sc.B > 0 || (p.sc.sph_tree && p.sc.bvh_nodes)) hipLaunchKernelGGL((k_render<false, true>), grid, block, 0, stream, p);
+	else hipLaunchKernelGGL((k_render<false, false>), grid, block, 0, stream, p);
 	return hipGetLastError();
 }
 
 hipError_t wbrt_launch_count(const RenderParams &p, hipStream_t stream)
 {
-	if (p.sc.B > 0) hipLaunchKernelGGL((k_render<true, true>), dim3(grid_for(p)), dim3(256), 0, stream, p);
-	else hipLaunchKernelGGL((k_render<true, false>), dim3(grid_for(p)), dim3(256), 0, stream, p);
+	const dim3 grid(grid_for(p, WBRT_RENDER_BLOCK)), block(WBRT_RENDER_BLOCK);
+	if (p.sc.B > 0) hipLaunchKernelGGL((k_render<true, true>), grid, block, 0, stream, p);
+	else hipLaunchKernelGGL((k_render<true, false>), grid, block, 0, stream, p);
 	return hipGetLastError();
 }
 
@@ -1370,7 +1370,7 @@ hipError_t wbrt_launch_cost_sort(const int *costs, int n, int pilot_spp, int *ti
 
 hipError_t wbrt_launch_ids(const RenderParams &p, hipStream_t stream)
 {
-	hipLaunchKernelGGL(k_primary_ids, dim3(grid_for(p)), dim3(256), 0, stream, p);
+	hipLaunchKernelGGL(k_primary_ids, dim3(grid_for(p, 256)), dim3(256), 0, stream, p);
 	return hipGetLastError();
 }
 
