@@ -163,7 +163,7 @@ int timed_launch(wbrt_context *ctx, const RenderParams &p, hipStream_t stream)
 	const long long total = (long long)p.bsx * p.bsy * p.nbx * p.nby;
 	if (ctx->lpt && total >= 65536 && total % 64 == 0 && p.spp >= 8 * ctx->pilot_spp)
 	{
-		int rc = ctx->costs.reserve((size_t)total * sizeof(int));
+		int rc = ctx->costs.reserve((size_t)(total + total / 64 + 1) * sizeof(int));
 		if (!rc) rc = ctx->order.reserve((size_t)(total / 64 + 1) * sizeof(int));
 		if (!rc) rc = ctx->tile_costs.reserve((size_t)(total / 64 + 1) * sizeof(int));
 		if (!rc) rc = ctx->hist.reserve(256 * sizeof(unsigned));
@@ -173,7 +173,8 @@ int timed_launch(wbrt_context *ctx, const RenderParams &p, hipStream_t stream)
 		pilot.costs = (int *)ctx->costs.p;
 		pilot.out = nullptr;
 		HIP_TRY(wbrt_launch_render(pilot, stream));
-		HIP_TRY(wbrt_launch_cost_sort((const int *)ctx->costs.p, (int)total, ctx->pilot_spp, (int *)ctx->tile_costs.p,
+		const bool walks = p.sc.bvh_nodes != nullptr;
+		HIP_TRY(wbrt_launch_cost_sort((const int *)ctx->costs.p, walks ? (const int *)ctx->costs.p + total : nullptr, (int)total, ctx->pilot_spp, (int *)ctx->tile_costs.p,
 		                              (unsigned *)ctx->hist.p, (int *)ctx->order.p, stream));
 		q.order = (const int *)ctx->order.p;
 	}
@@ -566,7 +567,7 @@ int wbrt_pixel_costs_(wbrt_context *ctx, const wbrt_camera *camera, int32_t *hos
 	rc = ctx->counters.reserve(bytes);
 	if (rc) return rc;
 	size_t cbytes = (size_t)p.width * p.height * sizeof(int32_t);
-	rc = ctx->ids.reserve(cbytes);
+	rc = ctx->ids.reserve(cbytes + cbytes / 64 + sizeof(int32_t)); // mesh scenes append one value per 64 work indices
 	if (rc) return rc;
 	HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, bytes, ctx->stream));
 	p.counters = (unsigned long long *)ctx->counters.p;

@@ -70,7 +70,8 @@ struct RenderParams
 	float *out;
 	int *ids;                       // primary-id launch only
 	unsigned long long *counters;   // counting launch only
-	int *costs;                     // pilot launch: loop iterations per work index (no image is written)
+	int *costs;                     // pilot launch: loop iterations per work index, then (mesh scenes) walk rounds per
+	                                // 64 work indices (no image is written)
 	const int *order;               // optional: waves (groups of 64 work indices) sorted by estimated cost, descending
 	const uint32_t *seeds;
 	SceneDev sc;
@@ -103,7 +104,8 @@ void wbrt_append_sphere_tree(const float4 *sph_geom, const float *radius, int S,
 hipError_t wbrt_launch_render(const RenderParams &p, hipStream_t stream);
 hipError_t wbrt_launch_count(const RenderParams &p, hipStream_t stream);
 hipError_t wbrt_launch_ids(const RenderParams &p, hipStream_t stream);
-hipError_t wbrt_launch_cost_sort(const int *costs, int n, int pilot_spp, int *tile_costs, unsigned *hist, int *order, hipStream_t stream);
+// walk: per-tile rounds of the hierarchy walk (mesh scenes), or null
+hipError_t wbrt_launch_cost_sort(const int *costs, const int *walk, int n, int pilot_spp, int *tile_costs, unsigned *hist, int *order, hipStream_t stream);
 hipError_t wbrt_launch_tonemap(const float *image, float scale, int width, int height, uint8_t *rgb8, hipStream_t stream);
 // evaluates the device's float / double primitives on arrays (known-answer tests)
 hipError_t wbrt_launch_math_probe(int op, const float *a, const float *b, float *out, int n, hipStream_t stream);

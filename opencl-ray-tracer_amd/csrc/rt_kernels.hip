@@ -1038,11 +1038,11 @@ __global__ __launch_bounds__(WBRT_RENDER_BLOCK) void k_render(const RenderParams
 			}
 			else if (sc.bvh_nodes)
 			{
-				// pilot launch: rounds of the walk join the tile's cost estimate (the sum over its
-				// lanes, so booked on one lane); weight 3 per round measured best (1..32 tried)
+				// pilot launch: the rounds of the walk (the same number in every lane) join the tile's
+				// cost estimate
 				int rounds = 0;
 				triangles_steal(sc, s_stack, s_steal[0], trace, walk_spheres, L.o, L.d, t, id, rounds);
-				if (p.costs && (threadIdx.x & 63) == 0) walk_cost += 3 * rounds;
+				if (p.costs) walk_cost += rounds;
 			}
 			else triangles_cooperative(sc, s_best[threadIdx.x >> 6], trace, L.o, L.d, t, id);
 		}
@@ -1201,7 +1201,9 @@ __global__ __launch_bounds__(WBRT_RENDER_BLOCK) void k_render(const RenderParams
 	}
 	if (p.costs) // pilot launch: only the loop iterations (ray segments) of each work index
 	{
-		if (w < (long long)p.bsx * p.bsy * p.nbx * p.nby) p.costs[w] = iterations + walk_cost;
+		const long long total = (long long)p.bsx * p.bsy * p.nbx * p.nby;
+		if (w < total) p.costs[w] = iterations;
+		if (MESH && (threadIdx.x & 63) == 0 && w < total) p.costs[total + (w >> 6)] = walk_cost; // per tile, after the per-pixel part
 		return;
 	}
 	if (w < (long long)p.bsx * p.bsy * p.nbx * p.nby)
@@ -1296,14 +1298,24 @@ __global__ void k_math_probe(int op, const float *a, const float *b, float *out,
 	out[i] = r;
 }
 
-// Cost of a wave's 64 work indices = sum of their pilot iteration counts, scaled into 0..255.
-__global__ void k_tile_cost(const int *costs, int n, int n_tiles, int shift, int *tile_costs)
+// Cost of a wave's 64 work indices, scaled into 0..255: the sum of their pilot iteration counts
+// plus 64 x the largest of them.  A wave lasts as long as its LONGEST pixel stream; tiles with a
+// few long streams among cheap ones (an object's edge against the sky) have a small sum, and
+// ranked by the sum alone they started late and were the last to finish (weights 16..512 tried).
+__global__ void k_tile_cost(const int *costs, const int *walk, int n, int n_tiles, int shift, int *tile_costs)
 {
 	const int tile = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
 	const int i = tile * 64 + (threadIdx.x & 63);
 	int c = (tile < n_tiles && i < n) ? costs[i] : 0;
-	for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
-	if ((threadIdx.x & 63) == 0 && tile < n_tiles) tile_costs[tile] = c >> shift;
+	int mx = c;
+	for (int off = 32; off > 0; off >>= 1)
+	{
+		c += __shfl_down(c, off, 64);
+		const int other = __shfl_down(mx, off, 64);
+		mx = other > mx ? other : mx;
+	}
+	// mesh scenes, where the walk is shared by the wave: sum + 3 per round of the walk (measured best)
+	if ((threadIdx.x & 63) == 0 && tile < n_tiles) tile_costs[tile] = walk ? (c + 3 * walk[tile]) >> shift : (c + 64 * mx) >> (shift + 1);
 }
 
 // Counting sort of indices by cost, descending (256 buckets).
@@ -1354,14 +1366,14 @@ hipError_t wbrt_launch_count(const RenderParams &p, hipStream_t stream)
 	return hipGetLastError();
 }
 
-hipError_t wbrt_launch_cost_sort(const int *costs, int n, int pilot_spp, int *tile_costs, unsigned *hist, int *order, hipStream_t stream)
+hipError_t wbrt_launch_cost_sort(const int *costs, const int *walk, int n, int pilot_spp, int *tile_costs, unsigned *hist, int *order, hipStream_t stream)
 {
 	const int n_tiles = (n + 63) / 64;
 	int shift = 0; // a tile whose 64 streams average 16 segments per sample lands in the last bucket
 	while (((64 * 16 * pilot_spp) >> shift) > 255) ++shift;
 	hipError_t e = hipMemsetAsync(hist, 0, 256 * sizeof(unsigned), stream);
 	if (e != hipSuccess) return e;
-	hipLaunchKernelGGL(k_tile_cost, dim3((n_tiles + 3) / 4), dim3(256), 0, stream, costs, n, n_tiles, shift, tile_costs);
+	hipLaunchKernelGGL(k_tile_cost, dim3((n_tiles + 3) / 4), dim3(256), 0, stream, costs, walk, n, n_tiles, shift, tile_costs);
 	hipLaunchKernelGGL(k_cost_hist, dim3(64), dim3(256), 0, stream, (const int *)tile_costs, n_tiles, hist);
 	hipLaunchKernelGGL(k_cost_scan, dim3(1), dim3(1), 0, stream, hist);
 	hipLaunchKernelGGL(k_cost_scatter, dim3(64), dim3(256), 0, stream, (const int *)tile_costs, n_tiles, hist, order);
