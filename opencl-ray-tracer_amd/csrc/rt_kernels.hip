@@ -582,6 +582,7 @@ __device__ __forceinline__ bool bvh_box(F3 o_near, F3 o_far, F3 inv, float mnx, 
 // Threads per workgroup of the render kernels: one wave.  Nothing is shared between the waves of
 // a workgroup, and single waves free their LDS and fill freed slots soonest.
 #define WBRT_RENDER_BLOCK 64
+#define WBRT_LDS_SPHERES 16 // sphere tables up to this size are copied to LDS (<= WBRT_RENDER_BLOCK)
 
 struct StealLds
 {
@@ -969,6 +970,18 @@ __global__ __launch_bounds__(WBRT_RENDER_BLOCK) void k_render(const RenderParams
 	__shared__ unsigned long long s_best[MESH && !STATS ? WBRT_RENDER_BLOCK / 64 : 1][64];
 	__shared__ int s_stack[MESH && !STATS ? WBRT_BVH_STACK : 1][WBRT_RENDER_BLOCK]; // one column per thread
 	__shared__ StealLds s_steal[1];
+	// the winner's centre, radius and material are read with a per-lane index once per segment:
+	// for small sphere counts from this per-wave copy (one LDS round trip instead of four
+	// vector loads on the wave's critical path)
+	__shared__ float4 s_sph[WBRT_LDS_SPHERES][3]; // center.xyz r^2 | albedo fuzz | radius ior type -
+	if (p.sc.S <= WBRT_LDS_SPHERES && (int)threadIdx.x < p.sc.S)
+	{
+		const float2 b = p.sc.sph_mat_b[threadIdx.x];
+		s_sph[threadIdx.x][0] = p.sc.sph_geom[threadIdx.x];
+		s_sph[threadIdx.x][1] = p.sc.sph_mat_a[threadIdx.x];
+		s_sph[threadIdx.x][2] = make_float4(p.sc.sph_radius[threadIdx.x], b.x, b.y, 0.0f);
+	}
+	__builtin_amdgcn_wave_barrier();
 	Counters<STATS> ctr;
 	const SceneDev &sc = p.sc;
 	long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1059,10 +1072,20 @@ __global__ __launch_bounds__(WBRT_RENDER_BLOCK) void k_render(const RenderParams
 				float2 mb;
 				if (id < sc.S)
 				{
-					const float4 g = sc.sph_geom[id];
-					outward = div3(hp - f3(g.x, g.y, g.z), sc.sph_radius[id]);
-					ma = sc.sph_mat_a[id];
-					mb = sc.sph_mat_b[id];
+					if (sc.S <= WBRT_LDS_SPHERES) // small sphere tables live in LDS (filled at kernel start)
+					{
+						const float4 g = s_sph[id][0], m = s_sph[id][1], q = s_sph[id][2];
+						outward = div3(hp - f3(g.x, g.y, g.z), q.x);
+						ma = m;
+						mb = make_float2(q.y, q.z);
+					}
+					else
+					{
+						const float4 g = sc.sph_geom[id];
+						outward = div3(hp - f3(g.x, g.y, g.z), sc.sph_radius[id]);
+						ma = sc.sph_mat_a[id];
+						mb = sc.sph_mat_b[id];
+					}
 				}
 				else
 				{
