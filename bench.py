@@ -211,9 +211,10 @@ def main():
             "roofline": {
                 "bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4),
-                # HBM bytes per frame from rocprofv3 PMC passes (profiles/r1/v4_lpt_summary.txt: WRITE_SIZE 10.8 MB +
-                # 2 x FETCH_SIZE 1.1 MB, gfx950 counts wide reads at half); algorithmic bytes are 11.06 MB image + 0.92 MB seeds
-                "traffic": 13.0e6 if args.config == "readme" else None, "traffic_unit": "bytes/frame (PMC, profiled run)",
+                # HBM bytes of the full (non-pilot) launch from rocprofv3 PMC passes (profiles/r1/final_headline_summary.txt and
+                # the per-dispatch values behind it): WRITE_SIZE 11.1 MB + 2 x FETCH_SIZE 3.65 MB (gfx950 tallies wide reads at
+                # half; an upper bound here); algorithmic bytes are 11.06 MB image + 0.92 MB seeds + 0.06 MB schedule
+                "traffic": 18.4e6 if args.config == "readme" else None, "traffic_unit": "bytes/launch (PMC, profiled run)",
                 "flops_per_launch": flops, "flop_per_path": round(flops / (cam.width * cam.height * spp), 2),
                 "note": "peak is the packed-FMA FP32 vector rate; results are bit-exact with a non-contracting IEEE build, so "
                         "counted FLOPs issue as separate mul/add (measured ceiling 0.87 G wave-inst/s/SIMD = 57 TFLOP/s)",
