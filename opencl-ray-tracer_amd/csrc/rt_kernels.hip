@@ -294,12 +294,15 @@ __device__ __forceinline__ bool spheres_fast(const SceneDev &sc, F3 o, F3 d, flo
 	float best_n = INFINITY, best_m = 0.0f, best_hb = 0.0f, best_disc = 0.0f;
 	bool best_second = false;
 	int id = -1;
+	// the scalar loads of the next two spheres are in flight while one sphere is tested
+	const int last = sc.S - 1;
 	float4 g_next = sc.S > 0 ? uniform_ld(sc.sph_geom, 0) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	float4 g_next2 = sc.S > 0 ? uniform_ld(sc.sph_geom, 1 < last ? 1 : last) : g_next;
 	for (int i = 0; i < sc.S; ++i)
 	{
-		// the next sphere's scalar load is issued before this sphere's arithmetic
 		const float4 g = g_next;
-		g_next = uniform_ld(sc.sph_geom, i + 1 < sc.S ? i + 1 : i);
+		g_next = g_next2;
+		g_next2 = uniform_ld(sc.sph_geom, i + 2 < last ? i + 2 : last);
 		F3 oc = o - f3(g.x, g.y, g.z);
 		float hb = dot(oc, d);
 		float cc = dot(oc, oc) - g.w;
