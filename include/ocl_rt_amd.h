@@ -136,9 +136,9 @@ int wbrt_synchronize(wbrt_context *ctx);
  *                         skipped only if a forward error bound of the reference's float
  *                         triangle test (at its own |det| >= 1e-5 cutoff) proves that none
  *                         of its triangles can be accepted: same result as the loop;
- *   WBRT_MESH_BVH         (default) as above with the box margin capped at 1e-4 of the
+ *   WBRT_MESH_BVH         (default) as above with the box margin capped at 2e-4 of the
  *                         ray's distance to the mesh.  Differs from the loop only for a ray
- *                         within about one degree of a triangle's plane that passes that
+ *                         within about half a degree of a triangle's plane that passes that
  *                         triangle at more than the margin: there the reference's own
  *                         accept/reject decision is rounding noise.
  * In both BVH modes scenes with 48 or more spheres also walk a hierarchy over the spheres

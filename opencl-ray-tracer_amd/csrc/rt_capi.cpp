@@ -71,7 +71,7 @@ struct wbrt_context
 	int bvh_depth[2] = {0, 0};
 	int mesh_mode = WBRT_MESH_BVH;
 	int bvh_steal_min_idle = 8;
-	float bvh_rho = 1e-4f; // WBRT_MESH_BVH: box margin as a fraction of the ray's distance bound
+	float bvh_rho = 2e-4f; // WBRT_MESH_BVH: box margin as a fraction of the ray's distance bound
 	DevBuf sky, seeds, image, ids, counters, rgb8, costs, tile_costs, order, hist;
 	int lpt = 1;        // longest-first scheduling from a pilot pass
 	int pilot_spp = 4;
