@@ -12,7 +12,12 @@
 //   * the closest hit is kept as (t, primitive id); hit point, normal and material are
 //     derived once per segment for the winner only;
 //   * primitives are repacked on upload (SceneDev): sphere centre + radius^2, triangle
-//     p0 + precomputed edges, triangles grouped per bounding box.
+//     p0 + precomputed edges, triangles grouped per bounding box;
+//   * mesh scenes and scenes with many spheres: hierarchies built on upload, walked by the
+//     whole wave with work handed between lanes (triangles_steal), hits merged by a 64-bit
+//     atomic min whose key order is the reference's tie rule;
+//   * waves are launched costliest first, from a pilot launch with a few samples per pixel
+//     (a frame lasts as long as its longest pixel stream).
 #include "rt_device.h"
 
 #include <math.h>
@@ -36,7 +41,6 @@ __device__ __forceinline__ F3 cross(F3 a, F3 b)
 __device__ __forceinline__ F3 unit(F3 a) { return a / sqrtf(dot(a, a)); }
 __device__ __forceinline__ F3 ld3(const float *p) { return f3(p[0], p[1], p[2]); }
 
-// ---------------------------------------------------------------- counters
 // Wave-uniform read of read-only scene data (same index in every lane): going through the
 // constant address space makes it a scalar load into SGPRs instead of a 64-lane vector load of
 // one address.  Only for buffers no kernel writes.
@@ -51,6 +55,7 @@ __device__ __forceinline__ float4 uniform_ld(const float4 *p, int i)
 #endif
 }
 
+// ---------------------------------------------------------------- counters
 template <bool ON> struct Counters;
 template <> struct Counters<false>
 {
