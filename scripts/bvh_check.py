@@ -7,10 +7,11 @@ from util import pkg, scene_main_cpp_with_mesh, bits
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 480
 SPP = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 mesh = sys.argv[3] if len(sys.argv) > 3 else "f1_car"
+seed = int(sys.argv[4]) if len(sys.argv) > 4 else 11
 scene = scene_main_cpp_with_mesh(mesh)
 cam = pkg.camera_main_cpp(W, SPP, 50)
 bw, bh = pkg.set_blocks(cam, 4)
-seeds = pkg.make_seeds(bw * bh, 11)
+seeds = pkg.make_seeds(bw * bh, seed)
 imgs = {}
 ctx = pkg.Context(0); ctx.upload_scene(scene); ctx.upload_seeds(seeds)
 for mode in (pkg.MESH_BVH, pkg.MESH_BVH_STRICT, pkg.MESH_LOOP):
