@@ -299,7 +299,10 @@ int wbrt_upload_scene(wbrt_context *ctx, const wbrt_sphere *spheres, int32_t S,
 		brange[(size_t)b] = make_int2(first[(size_t)b], first[(size_t)b + 1]);
 	}
 #define UP(buf, vec) do { rc = ctx->buf.upload((vec).data(), (vec).size() * sizeof((vec)[0])); if (rc) return rc; } while (0)
-	UP(sph_geom, geom); UP(sph_radius, radius); UP(sph_mat_a, mat_a); UP(sph_mat_b, mat_b);
+	// the kernel fetches small sphere tables as two 64-byte scalar loads: at least 8 entries exist
+	std::vector<float4> geom_padded(geom);
+	if (geom_padded.size() < 8) geom_padded.resize(8, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+	UP(sph_geom, geom_padded); UP(sph_radius, radius); UP(sph_mat_a, mat_a); UP(sph_mat_b, mat_b);
 	UP(tri_geom, tgeom); UP(tri_mat_a, tmat_a); UP(tri_mat_b, tmat_b); UP(tri_orig, torig);
 	UP(box_min, bmin); UP(box_max, bmax); UP(box_range, brange);
 	// A hierarchy over the spheres pays off for large sphere counts; it needs finite, moderate

@@ -290,16 +290,72 @@ __device__ __forceinline__ bool sky_texel_fast(const SceneDev &sc, F3 d, int &id
 // second root below tMin? closer than the best so far, later sphere winning ties) is taken
 // only when the margins make it certain; otherwise the lane reports failure and the caller
 // runs the exact loop.  The winner's root is then evaluated exactly, once.
+// Straight-line form: every sphere yields an interval [lo, hi] around the approximate numerator
+// of the root the reference would take (or +inf when it takes none); the loop keeps the smallest
+// and second smallest lower bound.  The candidate with the smallest lower bound is the reference's
+// winner whenever its upper bound lies below every other lower bound; any decision inside a
+// margin (which root, which sphere, NaN/inf anywhere) reports failure instead.
+struct SphereScan
+{
+	float a, T_lo, T_hi;
+	float min1, min2, bhi, bhb, bsd;
+	int id;
+	bool unc;
+	__device__ __forceinline__ void begin(float a_)
+	{
+		a = a_;
+		const float T = 0.001f * a;
+		T_lo = T * (1.0f - 4e-7f); T_hi = T * (1.0f + 4e-7f);
+		min1 = min2 = bhi = INFINITY; bhb = bsd = 0.0f; id = -1; unc = false;
+	}
+	__device__ __forceinline__ void test(F3 o, F3 d, float gx, float gy, float gz, float gw, int i)
+	{
+		F3 oc = o - f3(gx, gy, gz);
+		float hb = dot(oc, d);
+		float cc = dot(oc, oc) - gw;
+		float disc = hb * hb - a * cc;
+		const bool miss = disc < 0.0f;
+		if (!__ballot(!miss)) return; // no lane of the wave reaches this sphere
+		// hardware square root: 1 ulp, and (flushed) tiny arguments are covered by the absolute slack
+		const float sq = __builtin_amdgcn_sqrtf(disc);
+		const float n1 = -hb - sq, n2 = -hb + sq;
+		const float ms = __builtin_fmaf(2e-7f, sq, 1e-14f);
+		const float m1 = __builtin_fmaf(3e-7f, fabsf(n1), ms), m2 = __builtin_fmaf(3e-7f, fabsf(n2), ms);
+		const float lo1 = n1 - m1, hi1 = n1 + m1, lo2 = n2 - m2, hi2 = n2 + m2;
+		const bool f_ok = lo1 > T_hi, f_bad = hi1 < T_lo;   // first root certainly >= tMin / < tMin
+		const bool s_ok = lo2 > T_hi, s_bad = hi2 < T_lo;
+		const bool certain = miss | f_ok | (f_bad & (s_ok | s_bad));
+		const bool cand = f_ok | (f_bad & s_ok);            // false for a miss: sq is NaN there
+		unc |= !certain;
+		float lo = f_ok ? lo1 : lo2;
+		const float hi = f_ok ? hi1 : hi2;
+		lo = cand ? lo : INFINITY;
+		const float sd = f_ok ? -disc : disc;               // sign marks which root (both equal at 0)
+		const bool less = lo < min1;
+		min2 = fminf(min2, fmaxf(min1, lo));
+		min1 = fminf(min1, lo);
+		bhi = less ? hi : bhi;
+		bhb = less ? hb : bhb;
+		bsd = less ? sd : bsd;
+		id = less ? i : id;
+	}
+	__device__ __forceinline__ bool finish(float &t_out, int &id_out)
+	{
+		id_out = id;
+		t_out = INFINITY;
+		if (id >= 0)
+		{
+			const float sq = sqrtf(fabsf(bsd));
+			t_out = (__builtin_signbitf(bsd) ? (-bhb - sq) : (-bhb + sq)) / a;
+		}
+		return (a > 0.0f) & (a < 1e30f) & !unc & ((id < 0) | (bhi < min2));
+	}
+};
+
 __device__ __forceinline__ bool spheres_fast(const SceneDev &sc, F3 o, F3 d, float a, float &t_out, int &id_out)
 {
-	const float tmin = 0.001f;
-	bool ok = a > 0.0f && a < 1e30f;
-	const float T = tmin * a;
-	const float T_lo = T * (1.0f - 4e-7f), T_hi = T * (1.0f + 4e-7f);
-	float best_n = INFINITY, best_m = 0.0f, best_hb = 0.0f, best_disc = 0.0f;
-	bool best_second = false;
-	int id = -1;
-	// the scalar loads of the next two spheres are in flight while one sphere is tested
+	SphereScan s;
+	s.begin(a);
 	const int last = sc.S - 1;
 	float4 g_next = sc.S > 0 ? uniform_ld(sc.sph_geom, 0) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 	float4 g_next2 = sc.S > 0 ? uniform_ld(sc.sph_geom, 1 < last ? 1 : last) : g_next;
@@ -308,45 +364,9 @@ __device__ __forceinline__ bool spheres_fast(const SceneDev &sc, F3 o, F3 d, flo
 		const float4 g = g_next;
 		g_next = g_next2;
 		g_next2 = uniform_ld(sc.sph_geom, i + 2 < last ? i + 2 : last);
-		F3 oc = o - f3(g.x, g.y, g.z);
-		float hb = dot(oc, d);
-		float cc = dot(oc, oc) - g.w;
-		float disc = hb * hb - a * cc;
-		if (disc < 0.0f) continue;
-		ok = ok && (disc == 0.0f || (disc > 1e-30f && disc < 1e30f));
-		const float sq = __builtin_amdgcn_sqrtf(disc);
-		const float n1 = -hb - sq, n2 = -hb + sq;
-		// margin = |approximate - exact numerator| (1.5 ulp of the square root, plus the
-		// roundings of the two sums) + the distance below which two quotients may round
-		// to the same float
-		const float ms = 2e-7f * sq;
-		bool second = false;
-		float n = n1;
-		float m = __builtin_fmaf(3e-7f, fabsf(n1), ms);
-		if (n1 - m > T_hi) { }                      // first root certainly >= tMin
-		else if (n1 + m < T_lo)                      // first root certainly < tMin
-		{
-			second = true;
-			n = n2;
-			m = __builtin_fmaf(3e-7f, fabsf(n2), ms);
-			if (n2 - m > T_hi) { }
-			else if (n2 + m < T_lo) continue;        // both roots below tMin
-			else { ok = false; continue; }
-		}
-		else { ok = false; continue; }
-		if (n + m < best_n - best_m) { }             // certainly closer (or best is still +inf)
-		else if (n - m > best_n + best_m) continue;  // certainly farther
-		else { ok = false; continue; }
-		best_n = n; best_m = m; best_hb = hb; best_disc = disc; best_second = second; id = i;
+		s.test(o, d, g.x, g.y, g.z, g.w, i);
 	}
-	id_out = id;
-	t_out = INFINITY;
-	if (id >= 0)
-	{
-		const float sq = sqrtf(best_disc);
-		t_out = (best_second ? (-best_hb + sq) : (-best_hb - sq)) / a;
-	}
-	return ok;
+	return s.finish(t_out, id_out);
 }
 
 // ------------------------------------------------------------ intersection

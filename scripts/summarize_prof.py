@@ -30,4 +30,4 @@ for d in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write", "pmc_tcp"):
             continue
         print("  kernel %s" % k[:70])
         for c, vals in sorted(ctrs.items()):
-            print("    %-28s %18.1f  (n=%d)" % (c, sum(vals) / len(vals), len(vals)))
+            print("    %-28s %18.1f  (n=%d, max %.1f)" % (c, sum(vals) / len(vals), len(vals), max(vals)))
