@@ -66,17 +66,22 @@ def cpu_baseline(pkg, scene, cam, seeds):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None, help="default 20 (readme, mesh), 3 (uhd), 2 (stress)")
+    ap.add_argument("--warmup", type=int, default=None, help="default 3 (readme, mesh), 1 (uhd, stress)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--frames-in-flight", type=int, default=1,
                     help="throughput mode: steps alternate over this many contexts/streams so that the tail of one frame "
                          "overlaps the start of the next (default 1: one frame at a time, ms_per_step is a frame time)")
-    ap.add_argument("--config", choices=["readme", "mesh", "uhd"], default="readme",
+    ap.add_argument("--config", choices=["readme", "mesh", "uhd", "stress"], default="readme",
                     help="readme = headline (BASELINE.json configs[1]); mesh = configs[2]: main.cpp spheres + f1_car mesh, "
                          "1920x1080, 100 spp; uhd = configs[3]: README scene 3840x2160, 1000 spp as 8 seed shards of 125 spp "
-                         "split over the ranks (strong scaling)")
+                         "split over the ranks (strong scaling); stress = configs[4]: 500 random spheres + 100352-triangle "
+                         "mesh in 256 bounding boxes, 3840x2160, 500 spp as 8 seed shards of 63/62 spp (strong scaling)")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = {"uhd": 3, "stress": 2}.get(args.config, 20)
+    if args.warmup is None:
+        args.warmup = {"uhd": 1, "stress": 1}.get(args.config, 3)
 
     import torch
     import torch.distributed as dist
@@ -102,6 +107,8 @@ def main():
     pkg = entry.load_package()
     mg = __import__("importlib").import_module(entry.PKG_NAME + ".multi_gpu")
     spp = SPP
+    sharded = args.config in ("uhd", "stress")
+    shard_spp = None
     if args.config == "mesh":
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from util import scene_main_cpp_with_mesh  # builds the scene from the committed triangle soup
@@ -118,6 +125,15 @@ def main():
         cam = pkg.camera_readme(3840, spp, DEPTH)
         workload = ("README 5-sphere scene, 3840x2160, 1000 spp = 8 seed shards x 125 spp split over the ranks, depth 50, "
                     "4 blocks of 1920x1080 (BASELINE.json configs[3]); seed buffers (8.3 MB per shard) are uploaded inside the step")
+    elif args.config == "stress":
+        scene = pkg.scene_stress(500, 224, 224, 16, 16)
+        shards, spp = 8, 500
+        if shards % world:
+            raise SystemExit("--config stress splits 8 seed shards: use 1, 2, 4 or 8 GPUs")
+        shard_spp = mg.split_spp(spp, shards)
+        cam = pkg.camera_stress(3840, max(shard_spp), DEPTH)
+        workload = ("divergence stress: 500 random Lambertian/metal spheres + 100352-triangle mesh in 256 bounding boxes, 3840x2160, "
+                    "500 spp = 8 seed shards of 63/62 spp split over the ranks, depth 50, 4 blocks of 1920x1080 (BASELINE.json configs[4])")
     else:
         scene = pkg.scene_readme()
         cam = pkg.camera_readme(WIDTH, SPP, DEPTH)
@@ -127,7 +143,7 @@ def main():
     seeds = pkg.make_seeds(bw * bh, BASE_SEED, shard=rank)  # rank r renders seed shard r
 
     nfl = max(1, args.frames_in_flight)
-    if nfl > 1 and args.config == "uhd":
+    if nfl > 1 and sharded:
         raise SystemExit("--frames-in-flight applies to the one-launch-per-frame configurations")
     ctxs, frames, streams = [], [], []
     for k in range(nfl):
@@ -152,9 +168,9 @@ def main():
             t.copy_(h)
 
     def step():
-        if args.config == "uhd":
+        if sharded:
             mg.render_sharded_frame(ctx, cam, frame, shards, BASE_SEED, rank, world, stream=stream,
-                                    all_reduce=all_reduce if world > 1 else None)
+                                    all_reduce=all_reduce if world > 1 else None, shard_spp=shard_spp)
         elif nfl == 1:
             mg.render_step(ctx, cam, frame, total_spp=spp * world, stream=stream,
                            all_reduce=all_reduce if world > 1 else None)
@@ -188,11 +204,27 @@ def main():
         all_reduce(t, dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    paths_per_step = cam.width * cam.height * spp * (shards if args.config == "uhd" else world)
+    if args.config == "uhd":
+        paths_per_step = cam.width * cam.height * spp * shards
+    elif args.config == "stress":
+        paths_per_step = cam.width * cam.height * spp
+    else:
+        paths_per_step = cam.width * cam.height * spp * world
     result = None
     if rank == 0:
-        counters = ctx.count_events(cam)  # exact event counts of this rank's launch (untimed)
-        flops = pkg.algorithmic_flops(counters)
+        launch_paths = cam.width * cam.height * cam.samplesPerPixel
+        if args.config == "stress":
+            # the counting build runs the reference's sequential loops (every triangle of every hit box): counted on a
+            # 480x270 x 2 spp rendering of the same scene and scaled per path to one shard launch
+            small = pkg.camera_stress(480, 2, DEPTH)
+            sbw, sbh = pkg.set_blocks(small, BLOCKS)
+            ctx.upload_seeds(pkg.make_seeds(sbw * sbh, BASE_SEED))
+            counters = ctx.count_events(small)
+            launch_paths = cam.width * cam.height * (spp / shards)
+            flops = pkg.algorithmic_flops(counters) / (small.width * small.height * small.samplesPerPixel) * launch_paths
+        else:
+            counters = ctx.count_events(cam)  # exact event counts of this rank's launch (untimed)
+            flops = pkg.algorithmic_flops(counters)
         if nfl > 1:  # overlapping launches have no meaningful individual duration: price the frame rate instead
             kernel_ms, launches = dt * 1e3, args.steps
         k_ms = kernel_ms / max(launches, 1)
@@ -200,7 +232,7 @@ def main():
         result = {
             "metric": "Mpaths/s", "value": round(paths_per_step * args.steps / dt / 1e6, 2), "unit": "Mpaths/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if args.config == "uhd" else "weak",
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if sharded else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": workload,
@@ -215,19 +247,19 @@ def main():
                 # the per-dispatch values behind it): WRITE_SIZE 11.1 MB + 2 x FETCH_SIZE 3.65 MB (gfx950 tallies wide reads at
                 # half; an upper bound here); algorithmic bytes are 11.06 MB image + 0.92 MB seeds + 0.06 MB schedule
                 "traffic": 18.4e6 if args.config == "readme" else None, "traffic_unit": "bytes/launch (PMC, profiled run)",
-                "flops_per_launch": flops, "flop_per_path": round(flops / (cam.width * cam.height * spp), 2),
+                "flops_per_launch": flops, "flop_per_path": round(flops / launch_paths, 2),
                 "note": "peak is the packed-FMA FP32 vector rate; results are bit-exact with a non-contracting IEEE build, so "
                         "counted FLOPs issue as separate mul/add (measured ceiling 0.87 G wave-inst/s/SIMD = 57 TFLOP/s)",
             },
         }
-        if args.config == "mesh":
+        if args.config in ("mesh", "stress"):
             result["config"].pop("readme_published_gpu_frame_s", None)
             # the FLOP count prices every triangle test the reference's loop performs; the hierarchy walk
             # skips almost all of them, so this is a reference-equivalent work rate, not a hardware fraction
             result["roofline"]["frac"] = None
             result["roofline"]["note"] = ("reference-equivalent rate: FLOPs are those of the reference's per-box triangle loop "
                                           "(every triangle of a hit box tested); the kernel walks a hierarchy instead and executes far fewer")
-        if args.config == "uhd":
+        if sharded:
             result["config"].pop("readme_published_gpu_frame_s", None)
             result["config"]["parallelism"] = "8 seed shards / %d ranks + all-reduce(sum) of the %.1f MB accumulation buffer" % (
                 world, cam.width * cam.height * 12 / 1e6)

@@ -136,3 +136,25 @@ def test_single_rank_equals_reference_semantics():
     want = orc.Oracle(scene).render_frame(cam, seeds)  # the strict reference run (V = 1)
     got = frame.image().numpy() / np.float32(cam.samplesPerPixel)
     assert np.array_equal(bits(got), bits(want))
+
+
+def test_uneven_shard_sample_counts():
+    assert mg.split_spp(500, 8) == [63, 63, 63, 63, 62, 62, 62, 62]
+    assert mg.split_spp(8, 4) == [2, 2, 2, 2]
+    scene, cam = _case()
+    cam.samplesPerPixel = 7  # split over 3 shards as 3, 2, 2
+    spp = mg.split_spp(7, 3)
+    ctx = OracleContext(scene)
+    frame = mg.FrameBuffers(cam.width, cam.height, torch.device("cpu"))
+    mg.render_sharded_frame(ctx, cam, frame, 3, 9, 0, 1, shard_spp=spp)
+    bw, bh = int(cam.blockSize.x), int(cam.blockSize.y)
+    O = orc.Oracle(scene)
+    want = None
+    for v in range(3):
+        c = cam.copy()
+        c.samplesPerPixel = spp[v]
+        part = O.render_frame(c, pkg.make_seeds(bw * bh, 9, shard=v), out_mode=orc.OUT_SUM)
+        want = part if want is None else want + part
+    assert np.array_equal(bits(frame.accum.numpy()), bits(want.reshape(-1)))
+    pic = pkg.tonemap_host(want.reshape(cam.height, cam.width, 3), 1.0 / 7)
+    assert np.array_equal(frame.rgb8.numpy().reshape(pic.shape), pic)
