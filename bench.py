@@ -204,6 +204,20 @@ def main():
         all_reduce(t, dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # the same step with every launch scheduled from its own pilot launch (no costs carried over from the
+    # previous frame), for comparison: what a frame of a new view costs
+    pilot_ms = None
+    if nfl == 1 and not sharded:
+        ctx.set_schedule_reuse(False)
+        step()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            step()
+        barrier()
+        pilot_ms = (time.perf_counter() - t1) / 5 * 1e3
+        ctx.set_schedule_reuse(True)
+
     if args.config == "uhd":
         paths_per_step = cam.width * cam.height * spp * shards
     elif args.config == "stress":
@@ -238,6 +252,9 @@ def main():
                 "workload": workload,
                 "paths_per_step": paths_per_step, "parallelism": "spp-shard x%d + all-reduce(sum) of the %.2f MB accumulation buffer" % (world, cam.width * cam.height * 12 / 1e6),
                 "kernel_ms_per_launch": round(k_ms, 4), "frames_in_flight": nfl,
+                "schedule": "waves launched costliest first; costs recorded by the previous launch of the same view "
+                            "(a launch without one runs a 4-spp pilot launch first)",
+                "ms_per_step_with_pilot_every_frame": None if pilot_ms is None else round(pilot_ms, 4),
                 "readme_published_gpu_frame_s": 0.38,
             },
             "roofline": {

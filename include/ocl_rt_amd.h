@@ -149,6 +149,15 @@ int wbrt_synchronize(wbrt_context *ctx);
 enum { WBRT_MESH_LOOP = 0, WBRT_MESH_BVH_STRICT = 1, WBRT_MESH_BVH = 2 };
 int wbrt_set_mesh_mode(wbrt_context *ctx, int mode);
 
+/* Launch schedule.  Waves are launched costliest pixel streams first.  The costs come from the
+ * previous render launch of the same view (camera vectors, aperture, image and block size, block
+ * offset, depth, scene, mesh mode): every launch records the ray segments each pixel stream took.
+ * A launch without such a predecessor is preceded by a pilot launch with 4 samples per pixel.
+ * Seeds and sample count may differ between the launches (seed shards of one frame share the
+ * schedule).  The schedule never changes a result.  reuse = 0 makes every launch run its own pilot
+ * (default 1).  No counterpart in the reference (one NDRange per block, main.cpp:240). */
+int wbrt_set_schedule_reuse(wbrt_context *ctx, int reuse);
+
 /* kernel-only timing: when enabled every render launch is bracketed by HIP events on
  * its own stream.  wbrt_get_timing synchronises and returns the sum over launches since
  * the last reset. */

@@ -107,6 +107,7 @@ _SIGNATURES = {
     "wbrt_tonemap_device": (C.c_int, [_P, _P, C.c_float, C.c_int32, C.c_int32, _P, _P]),
     "wbrt_synchronize": (C.c_int, [_P]),
     "wbrt_set_mesh_mode": (C.c_int, [_P, C.c_int]),
+    "wbrt_set_schedule_reuse": (C.c_int, [_P, C.c_int]),
     "wbrt_set_timing": (C.c_int, [_P, C.c_int]),
     "wbrt_get_timing": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_int]),
     "wbrt_device_info": (C.c_int, [_P, C.c_char_p, C.c_size_t]),
@@ -424,6 +425,10 @@ class Context:
     def set_mesh_mode(self, mode):
         """MESH_LOOP, MESH_BVH_STRICT or MESH_BVH (default); see include/ocl_rt_amd.h."""
         _check(lib().wbrt_set_mesh_mode(self._h, int(mode)))
+
+    def set_schedule_reuse(self, on=True):
+        """Schedule a launch from the costs its predecessor recorded (default) or always from a pilot launch."""
+        _check(lib().wbrt_set_schedule_reuse(self._h, 1 if on else 0))
 
     def set_timing(self, on=True):
         _check(lib().wbrt_set_timing(self._h, 1 if on else 0))

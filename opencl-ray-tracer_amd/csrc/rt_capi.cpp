@@ -59,6 +59,16 @@ struct DevBuf
 
 } // namespace
 
+// What the recorded per-pixel costs of a launch depend on (apart from seeds and sample count).
+struct ViewKey
+{
+	float cam[18];
+	float aperture;
+	int dims[10];
+	unsigned long long scene_generation;
+	int walks;
+};
+
 struct wbrt_context
 {
 	int device = 0;
@@ -75,6 +85,10 @@ struct wbrt_context
 	DevBuf sky, seeds, image, ids, counters, rgb8, costs, tile_costs, order, hist;
 	int lpt = 1;        // longest-first scheduling from a pilot pass
 	int pilot_spp = 4;
+	int reuse_costs = 1;          // schedule a launch from the counts its predecessor recorded (same view)
+	int recorded_spp = 0;         // 0: nothing recorded
+	ViewKey recorded_view = {};
+	unsigned long long scene_generation = 0;
 	SceneDev sc{};
 	bool have_scene = false, have_sky = false, have_bvh = false, have_sphere_tree = false;
 	int sphere_tree_min = 48;  // sphere count from which the render build walks a sphere hierarchy
@@ -168,15 +182,37 @@ int timed_launch(wbrt_context *ctx, const RenderParams &p, hipStream_t stream)
 		if (!rc) rc = ctx->tile_costs.reserve((size_t)(total / 64 + 1) * sizeof(int));
 		if (!rc) rc = ctx->hist.reserve(256 * sizeof(unsigned));
 		if (rc) return rc;
-		RenderParams pilot = p;
-		pilot.spp = ctx->pilot_spp;
-		pilot.costs = (int *)ctx->costs.p;
-		pilot.out = nullptr;
-		HIP_TRY(wbrt_launch_render(pilot, stream));
-		const bool walks = p.sc.bvh_nodes != nullptr;
-		HIP_TRY(wbrt_launch_cost_sort((const int *)ctx->costs.p, walks ? (const int *)ctx->costs.p + total : nullptr, (int)total, ctx->pilot_spp, (int *)ctx->tile_costs.p,
+		// The full launch records the exact counts of every pixel stream; while the view (camera,
+		// tiling, depth, scene, mesh mode) stays the same they price the next launch, whatever its
+		// seeds or sample count, and no pilot launch is needed.  The schedule never changes a result.
+		ViewKey key;
+		std::memset(&key, 0, sizeof key);
+		std::memcpy(key.cam, p.org, sizeof key.cam);
+		key.aperture = p.aperture;
+		const int dims[] = { p.width, p.height, p.max_depth, p.bsx, p.bsy, p.nbx, p.nby, p.off_bx, p.off_by, ctx->mesh_mode };
+		std::memcpy(key.dims, dims, sizeof dims);
+		key.scene_generation = ctx->scene_generation;
+		key.walks = p.sc.bvh_nodes != nullptr;
+		int cost_spp = ctx->pilot_spp;
+		if (ctx->reuse_costs && ctx->recorded_spp > 0 && std::memcmp(&key, &ctx->recorded_view, sizeof key) == 0)
+			cost_spp = ctx->recorded_spp;
+		else
+		{
+			RenderParams pilot = p;
+			pilot.spp = ctx->pilot_spp;
+			pilot.costs = (int *)ctx->costs.p;
+			pilot.out = nullptr;
+			HIP_TRY(wbrt_launch_render(pilot, stream));
+		}
+		HIP_TRY(wbrt_launch_cost_sort((const int *)ctx->costs.p, key.walks ? (const int *)ctx->costs.p + total : nullptr, (int)total, cost_spp, (int *)ctx->tile_costs.p,
 		                              (unsigned *)ctx->hist.p, (int *)ctx->order.p, stream));
 		q.order = (const int *)ctx->order.p;
+		if (ctx->reuse_costs)
+		{
+			q.record = (int *)ctx->costs.p;
+			std::memcpy(&ctx->recorded_view, &key, sizeof key);
+			ctx->recorded_spp = p.spp;
+		}
 	}
 	HIP_TRY(wbrt_launch_render(q, stream));
 	if (ctx->timing)
@@ -214,6 +250,7 @@ int wbrt_create(int device_ordinal, wbrt_context **out)
 	if (const char *v = std::getenv("WBRT_SPHERE_TREE_MIN")) ctx->sphere_tree_min = std::atoi(v);
 	if (const char *v = std::getenv("WBRT_BVH_MIN_IDLE")) ctx->bvh_steal_min_idle = std::atoi(v);
 	if (const char *v = std::getenv("WBRT_BVH_RHO")) { float r = (float)std::atof(v); if (r > 0.0f) ctx->bvh_rho = r; }
+	if (const char *v = std::getenv("WBRT_REUSE_COSTS")) ctx->reuse_costs = std::atoi(v) != 0;
 	if (const char *v = std::getenv("WBRT_PILOT_SPP")) ctx->pilot_spp = std::atoi(v) > 0 ? std::atoi(v) : 4;
 	*out = ctx;
 	return WBRT_OK;
@@ -361,6 +398,7 @@ int wbrt_upload_scene(wbrt_context *ctx, const wbrt_sphere *spheres, int32_t S,
 	sc.sph_geom = (const float4 *)ctx->sph_geom.p; sc.sph_radius = (const float *)ctx->sph_radius.p;
 	sc.sph_mat_a = (const float4 *)ctx->sph_mat_a.p; sc.sph_mat_b = (const float2 *)ctx->sph_mat_b.p;
 	sc.S = S;
+	ctx->scene_generation++;
 	sc.tri_geom = (const float4 *)ctx->tri_geom.p; sc.tri_mat_a = (const float4 *)ctx->tri_mat_a.p;
 	sc.tri_mat_b = (const float2 *)ctx->tri_mat_b.p; sc.tri_orig = (const int *)ctx->tri_orig.p;
 	sc.T = Tg;
@@ -504,6 +542,14 @@ int wbrt_synchronize(wbrt_context *ctx)
 	int rc = bind(ctx);
 	if (rc) return rc;
 	HIP_TRY(hipDeviceSynchronize());
+	return WBRT_OK;
+}
+
+int wbrt_set_schedule_reuse(wbrt_context *ctx, int reuse)
+{
+	if (!ctx) return fail(WBRT_ERR_INVALID, "null context");
+	ctx->reuse_costs = reuse != 0;
+	ctx->recorded_spp = 0;
 	return WBRT_OK;
 }
 

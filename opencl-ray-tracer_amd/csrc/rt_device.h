@@ -72,6 +72,8 @@ struct RenderParams
 	unsigned long long *counters;   // counting launch only
 	int *costs;                     // pilot launch: loop iterations per work index, then (mesh scenes) walk rounds per
 	                                // 64 work indices (no image is written)
+	int *record;                    // optional, full launch: the same counts as `costs`, written next to the image
+	                                // (indexed by work index, whatever the launch order)
 	const int *order;               // optional: waves (groups of 64 work indices) sorted by estimated cost, descending
 	const uint32_t *seeds;
 	SceneDev sc;

@@ -1083,7 +1083,7 @@ __global__ __launch_bounds__(WBRT_RENDER_BLOCK) void k_render(const RenderParams
 				// cost estimate
 				int rounds = 0;
 				triangles_steal(sc, s_stack, s_steal[0], trace, walk_spheres, L.o, L.d, t, id, rounds);
-				if (p.costs) walk_cost += rounds;
+				if (p.costs || p.record) walk_cost += rounds;
 			}
 			else triangles_cooperative(sc, s_best[threadIdx.x >> 6], trace, L.o, L.d, t, id);
 		}
@@ -1259,6 +1259,13 @@ __global__ __launch_bounds__(WBRT_RENDER_BLOCK) void k_render(const RenderParams
 	}
 	if (w < (long long)p.bsx * p.bsy * p.nbx * p.nby)
 	{
+		if (p.record) // the next frame of the same view is scheduled from these counts instead of a pilot launch
+		{
+			const long long total = (long long)p.bsx * p.bsy * p.nbx * p.nby;
+			const long long at = p.order ? (long long)p.order[w >> 6] * 64 + (w & 63) : w;
+			p.record[at] = iterations;
+			if (MESH && (threadIdx.x & 63) == 0) p.record[total + (at >> 6)] = walk_cost;
+		}
 		const int row = gid / p.bsx + p.bsy * by, colx = gid % p.bsx + p.bsx * bx;
 		float *dst = p.out + 3 * ((size_t)row * p.out_w + colx);
 		F3 r = L.sum;

@@ -309,6 +309,37 @@ def test_output_modes_and_shard_sum(gpu_ctx):
     assert np.array_equal(bits(acc), bits((sums[0] + sums[1]) + sums[2]))
 
 
+@pytest.mark.parametrize("name", ["readme", "stress"])
+def test_schedule_reuse_never_changes_a_result(gpu_ctx, name):
+    """Launches scheduled from a pilot, from the previous launch's recorded costs (same and other seeds,
+    other sample count) and after a change of view all give the oracle's image."""
+    if name == "readme":
+        scene, cam = pkg.scene_readme(), pkg.camera_readme(384, 32, 50)
+    else:
+        scene, cam = pkg.scene_stress(40, 24, 24, 4, 4), pkg.camera_stress(384, 32, 50)
+    bw, bh = pkg.set_blocks(cam, 4)
+    assert cam.width * cam.height >= 65536  # large enough for the longest-first schedule
+    gpu_ctx.upload_scene(scene)
+    O = orc.Oracle(scene)
+    seeds = [pkg.make_seeds(bw * bh, 31, shard=v) for v in range(2)]
+    want = [O.render_frame(cam, s, math_mode=orc.MATH_PORTABLE, threads=8) for s in seeds]
+    gpu_ctx.set_schedule_reuse(True)
+    gpu_ctx.upload_seeds(seeds[0])
+    first = gpu_ctx.render_frame(cam)       # pilot launch
+    second = gpu_ctx.render_frame(cam)      # recorded costs
+    gpu_ctx.upload_seeds(seeds[1])
+    third = gpu_ctx.render_frame(cam)       # recorded costs, other seeds
+    assert np.array_equal(bits(first), bits(want[0])) and np.array_equal(bits(second), bits(want[0]))
+    assert np.array_equal(bits(third), bits(want[1]))
+    more = cam.copy()
+    more.samplesPerPixel = 40
+    got = gpu_ctx.render_frame(more)        # recorded costs, other sample count
+    assert np.array_equal(bits(got), bits(O.render_frame(more, seeds[1], math_mode=orc.MATH_PORTABLE, threads=8)))
+    gpu_ctx.set_schedule_reuse(False)
+    assert np.array_equal(bits(gpu_ctx.render_frame(cam)), bits(want[1]))
+    gpu_ctx.set_schedule_reuse(True)
+
+
 def test_tonemap_device_equals_host(gpu_ctx):
     import torch
     scene, cam = pkg.scene_readme(), pkg.camera_readme(160, 4, 50)
