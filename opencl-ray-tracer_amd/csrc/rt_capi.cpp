@@ -350,6 +350,15 @@ int wbrt_upload_scene(wbrt_context *ctx, const wbrt_sphere *spheres, int32_t S,
 		const float v[4] = { spheres[i].center.x, spheres[i].center.y, spheres[i].center.z, spheres[i].radius };
 		for (float x : v) if (!(std::fabs(x) < 1e8f)) sphere_tree = false;
 	}
+	// the margin-checked sphere scan assumes that no intermediate of the reference's sphere test can
+	// overflow: coordinates and radii below 1e8 (scenes outside that range take the exact loop)
+	bool spheres_moderate = true;
+	for (int i = 0; i < S && spheres_moderate; ++i)
+	{
+		const float v[4] = { spheres[i].center.x, spheres[i].center.y, spheres[i].center.z, spheres[i].radius };
+		for (float x : v) if (!(std::fabs(x) < 1e8f)) spheres_moderate = false;
+	}
+	ctx->sc.sph_moderate = spheres_moderate ? 1 : 0;
 	// hierarchies (render build only; the counting and primary-id builds keep the loops)
 	for (int variant = 0; variant < 2 && (Tg > 0 || sphere_tree); ++variant)
 	{

@@ -29,6 +29,7 @@ struct SceneDev
 	const float4 *sph_mat_a;  // [S] albedo.rgb, fuzz
 	const float2 *sph_mat_b;  // [S] ior, type (int bits)
 	int S;
+	int sph_moderate;         // 1: every centre coordinate and radius is finite and below 1e8
 	// triangles grouped by bounding-box index (stable), 12 floats each:
 	//   p0.xyz e0.x | e0.yz e1.xy | e1.z 0 0 0     with e0 = p1-p0, e1 = p2-p0
 	const float4 *tri_geom;   // [3*T']

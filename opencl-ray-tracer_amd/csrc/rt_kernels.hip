@@ -88,22 +88,23 @@ template <> struct Counters<true>
 // --------------------------------------------------------------------- RNG
 // gpu_kernel.cl:582-591: 48-bit LCG s' = (s*0x5DEECE66D + 0xB) mod 2^48; the float is
 // bits 47..16 of the new state converted with round-to-nearest and divided by 2^32.
-// The state is held as lo (bits 0..31) and hi (bits 32..47).  With M = 0xDEECE66D + 5*2^32:
-//   s*M + 0xB == lo*0xDEECE66D + 0xB + ((lo*5 + hi*0xDEECE66D) << 32)      (mod 2^48)
+// The 48-bit state s is held shifted left by 16 in a 64-bit pair: hi = bits 47..16 of s (exactly the
+// integer the float is made of), lo = bits 15..0 of s in its upper half.  (s << 16) * M mod 2^64 is
+// (s * M mod 2^48) << 16, so with M = 0xDEECE66D + 5*2^32 one step is
+//   lo*0xDEECE66D + (0xB << 16)  (64-bit)  +  ((lo*5 + hi*0xDEECE66D) << 32).
 // Scaling by a power of two is exact, so callers fold the 2^-32 into a fused multiply-add
 // (see unit()/bipolar()): fma(top, 2^-31, -1) is bit-identical to (top*2^-32)*2 - 1.
 struct Rng
 {
 	unsigned lo, hi;
-	__device__ __forceinline__ void seed(unsigned s32) { lo = s32; hi = 0; }
+	__device__ __forceinline__ void seed(unsigned s32) { lo = s32 << 16; hi = s32 >> 16; }
 	// advances the state, returns float(state >> 16) (an integer value in [0, 2^32])
 	__device__ __forceinline__ float next_top()
 	{
-		const unsigned long long p = (unsigned long long)lo * 0xDEECE66Du + 0xBu;
-		const unsigned upper = (unsigned)(p >> 32) + (lo << 2) + lo + hi * 0xE66Du; // only 16 bits matter
+		const unsigned long long p = (unsigned long long)lo * 0xDEECE66Du + 0xB0000u;
+		hi = (unsigned)(p >> 32) + (lo << 2) + lo + hi * 0xDEECE66Du;
 		lo = (unsigned)p;
-		hi = upper & 0xFFFFu;
-		return (float)((hi << 16) | (lo >> 16));
+		return (float)hi;
 	}
 	// the reference's draw in [0,1]
 	__device__ __forceinline__ float next() { return next_top() * 2.3283064365386963e-10f; }
@@ -291,22 +292,23 @@ __device__ __forceinline__ bool sky_texel_fast(const SceneDev &sc, F3 d, int &id
 // only when the margins make it certain; otherwise the lane reports failure and the caller
 // runs the exact loop.  The winner's root is then evaluated exactly, once.
 // Straight-line form: every sphere yields an interval [lo, hi] around the approximate numerator
-// of the root the reference would take (or +inf when it takes none); the loop keeps the smallest
-// and second smallest lower bound.  The candidate with the smallest lower bound is the reference's
-// winner whenever its upper bound lies below every other lower bound; any decision inside a
-// margin (which root, which sphere, NaN/inf anywhere) reports failure instead.
+// of the root the reference would take (lo = +inf when it certainly takes none); the loop keeps the
+// smallest and second smallest lower bound.  The candidate with the smallest lower bound is the
+// reference's winner whenever its upper bound lies below every other lower bound.  A root whose
+// comparison with tMin falls inside the margin gets lo = -1 or hi = +inf, which fails that check.
+// Bounds are positive floats, +inf or negative, so they are ordered as signed integers.
+// Requires |o| < 1e8, 1e-20 < a < 1e16 and sphere data below 1e8 (no overflow, no NaN in disc).
 struct SphereScan
 {
 	float a, T_lo, T_hi;
-	float min1, min2, bhi, bhb, bsd;
-	int id;
-	bool unc;
+	float bhi, bhb, bsd;
+	int min1, min2, id;
 	__device__ __forceinline__ void begin(float a_)
 	{
 		a = a_;
 		const float T = 0.001f * a;
 		T_lo = T * (1.0f - 4e-7f); T_hi = T * (1.0f + 4e-7f);
-		min1 = min2 = bhi = INFINITY; bhb = bsd = 0.0f; id = -1; unc = false;
+		min1 = min2 = 0x7f800000; bhi = INFINITY; bhb = bsd = 0.0f; id = -1;
 	}
 	__device__ __forceinline__ void test(F3 o, F3 d, float gx, float gy, float gz, float gw, int i)
 	{
@@ -314,32 +316,32 @@ struct SphereScan
 		float hb = dot(oc, d);
 		float cc = dot(oc, oc) - gw;
 		float disc = hb * hb - a * cc;
-		const bool miss = disc < 0.0f;
-		if (!__ballot(!miss)) return; // no lane of the wave reaches this sphere
-		// hardware square root: 1 ulp, and (flushed) tiny arguments are covered by the absolute slack
+		if (!__ballot(!(disc < 0.0f))) return; // no lane of the wave reaches this sphere
+		// hardware square root: 1 ulp, (flushed) tiny arguments are covered by the absolute slack; NaN for
+		// a miss, and every comparison below is written so that NaN means "no root here"
 		const float sq = __builtin_amdgcn_sqrtf(disc);
 		const float n1 = -hb - sq, n2 = -hb + sq;
-		const float ms = __builtin_fmaf(2e-7f, sq, 1e-14f);
-		const float m1 = __builtin_fmaf(3e-7f, fabsf(n1), ms), m2 = __builtin_fmaf(3e-7f, fabsf(n2), ms);
-		const float lo1 = n1 - m1, hi1 = n1 + m1, lo2 = n2 - m2, hi2 = n2 + m2;
-		const bool f_ok = lo1 > T_hi, f_bad = hi1 < T_lo;   // first root certainly >= tMin / < tMin
-		const bool s_ok = lo2 > T_hi, s_bad = hi2 < T_lo;
-		const bool certain = miss | f_ok | (f_bad & (s_ok | s_bad));
-		const bool cand = f_ok | (f_bad & s_ok);            // false for a miss: sq is NaN there
-		unc |= !certain;
-		float lo = f_ok ? lo1 : lo2;
-		const float hi = f_ok ? hi1 : hi2;
-		lo = cand ? lo : INFINITY;
-		const float sd = f_ok ? -disc : disc;               // sign marks which root (both equal at 0)
-		const bool less = lo < min1;
-		min2 = fminf(min2, fmaxf(min1, lo));
-		min1 = fminf(min1, lo);
+		// |approximate - exact numerator| (1.5 ulp of the root, roundings of the sums) + the distance
+		// below which two quotients may round to the same float: at most 5e-7 (|hb| + sq)
+		const float m = __builtin_fmaf(5e-7f, fabsf(hb) + sq, 1e-14f);
+		const float lo1 = n1 - m, hi1 = n1 + m, lo2 = n2 - m, hi2 = n2 + m;
+		const bool f_ok = lo1 > T_hi, f_bad = !(hi1 >= T_lo);   // first root certainly >= tMin / < tMin
+		const bool s_ok = lo2 > T_hi, s_bad = !(hi2 >= T_lo);
+		float lo = f_bad ? (s_bad ? INFINITY : lo2) : -1.0f;
+		lo = f_ok ? lo1 : lo;
+		float hi = (f_bad & s_ok) ? hi2 : INFINITY;
+		hi = f_ok ? hi1 : hi;
+		const float sd = f_ok ? -disc : disc;                   // sign marks which root (both equal at 0)
+		const int ilo = __float_as_int(lo);
+		const bool less = ilo < min1;
+		min2 = min(min2, max(min1, ilo));
+		min1 = min(min1, ilo);
 		bhi = less ? hi : bhi;
 		bhb = less ? hb : bhb;
 		bsd = less ? sd : bsd;
 		id = less ? i : id;
 	}
-	__device__ __forceinline__ bool finish(float &t_out, int &id_out)
+	__device__ __forceinline__ bool finish(bool in_range, float &t_out, int &id_out)
 	{
 		id_out = id;
 		t_out = INFINITY;
@@ -348,7 +350,7 @@ struct SphereScan
 			const float sq = sqrtf(fabsf(bsd));
 			t_out = (__builtin_signbitf(bsd) ? (-bhb - sq) : (-bhb + sq)) / a;
 		}
-		return (a > 0.0f) & (a < 1e30f) & !unc & ((id < 0) | (bhi < min2));
+		return in_range & ((id < 0) | (bhi < __int_as_float(min2)));
 	}
 };
 
@@ -356,6 +358,8 @@ __device__ __forceinline__ bool spheres_fast(const SceneDev &sc, F3 o, F3 d, flo
 {
 	SphereScan s;
 	s.begin(a);
+	const bool in_range = sc.sph_moderate && a > 1e-20f && a < 1e16f && fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) < 1e8f;
+	// the scalar loads of the next two spheres are in flight while one sphere is tested
 	const int last = sc.S - 1;
 	float4 g_next = sc.S > 0 ? uniform_ld(sc.sph_geom, 0) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 	float4 g_next2 = sc.S > 0 ? uniform_ld(sc.sph_geom, 1 < last ? 1 : last) : g_next;
@@ -366,7 +370,7 @@ __device__ __forceinline__ bool spheres_fast(const SceneDev &sc, F3 o, F3 d, flo
 		g_next2 = uniform_ld(sc.sph_geom, i + 2 < last ? i + 2 : last);
 		s.test(o, d, g.x, g.y, g.z, g.w, i);
 	}
-	return s.finish(t_out, id_out);
+	return s.finish(in_range, t_out, id_out);
 }
 
 // ------------------------------------------------------------ intersection
@@ -1373,7 +1377,14 @@ __global__ void k_tile_cost(const int *costs, const int *walk, int n, int n_tile
 		mx = other > mx ? other : mx;
 	}
 	// mesh scenes, where the walk is shared by the wave: sum + 3 per round of the walk (measured best)
-	if ((threadIdx.x & 63) == 0 && tile < n_tiles) tile_costs[tile] = walk ? (c + 3 * walk[tile]) >> shift : (c + 64 * mx) >> (shift + 1);
+	if ((threadIdx.x & 63) == 0 && tile < n_tiles) 
+#if WBRT_TILE_RANK == 1
+		tile_costs[tile] = walk ? (c + 3 * walk[tile]) >> shift : (64 * mx) >> shift;
+#elif WBRT_TILE_RANK == 2
+		tile_costs[tile] = walk ? (c + 3 * walk[tile]) >> shift : (c + 192 * mx) >> (shift + 2);
+#else
+		tile_costs[tile] = walk ? (c + 3 * walk[tile]) >> shift : (c + 64 * mx) >> (shift + 1);
+#endif
 }
 
 // Counting sort of indices by cost, descending (256 buckets).

@@ -13,7 +13,7 @@ def run(label, **env):
         os.environ[k] = str(v)
     ctx = pkg.Context(0)
     ctx.upload_scene(scene); ctx.upload_seeds(seeds)
-    for _ in range(2): ctx.render_frame_device(cam, buf.data_ptr())
+    for _ in range(3): ctx.render_frame_device(cam, buf.data_ptr())
     ctx.synchronize(); ctx.set_timing(True)
     for _ in range(12): ctx.render_frame_device(cam, buf.data_ptr())
     ctx.synchronize(); ms, n = ctx.get_timing()
