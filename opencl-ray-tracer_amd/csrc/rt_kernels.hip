@@ -192,9 +192,12 @@ __device__ __forceinline__ F3 sky_lookup(const SceneDev &sc, F3 dir)
 // zero / non-finite operands) the compiler's full IEEE division is used instead.
 __device__ __forceinline__ F3 div3(F3 num, float den)
 {
-	const float lo = 0x1p-40f, hi = 0x1p40f;
+	// all four magnitudes inside [2^-40, 2^40]; a NaN operand slips through min/max and yields NaN from
+	// the sequence below as it does from a division
 	const float ad = fabsf(den), ax = fabsf(num.x), ay = fabsf(num.y), az = fabsf(num.z);
-	const bool safe = ad >= lo && ad <= hi && ax >= lo && ax <= hi && ay >= lo && ay <= hi && az >= lo && az <= hi;
+	const float smallest = fminf(fminf(fminf(ax, ay), az), ad);
+	const float largest = fmaxf(fmaxf(fmaxf(ax, ay), az), ad);
+	const bool safe = smallest >= 0x1p-40f && largest <= 0x1p40f;
 	float y = __builtin_amdgcn_rcpf(den);
 	const float e = __builtin_fmaf(-den, y, 1.0f);
 	y = __builtin_fmaf(e, y, y);
@@ -1313,7 +1316,7 @@ __global__ void k_tonemap(const float *image, float scale, int width, int height
 }
 
 // op: 0 a/b, 1 sqrtf(a), 2 atan2(a,b), 3 asin(a), 4 a^5, 5 rng float of seed bits a (32-bit) after b draws,
-// 6 shared-reciprocal division a/b, 7/8 sky texel index (fast with fallback / exact)
+// 6 shared-reciprocal division a/b, 7/8 sky texel index (fast with fallback / exact), 9 division by a constant
 __global__ void k_math_probe(int op, const float *a, const float *b, float *out, int n)
 {
 	int i = blockIdx.x * blockDim.x + threadIdx.x;
