@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--steps", type=int, default=None, help="default 20 (readme, mesh), 3 (uhd), 2 (stress)")
     ap.add_argument("--warmup", type=int, default=None, help="default 3 (readme, mesh), 1 (uhd, stress)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pilot-comparison", action="store_true",
+                    help="skip the untimed extra frames that price a pilot launch before every frame (profiling runs)")
     ap.add_argument("--frames-in-flight", type=int, default=1,
                     help="throughput mode: steps alternate over this many contexts/streams so that the tail of one frame "
                          "overlaps the start of the next (default 1: one frame at a time, ms_per_step is a frame time)")
@@ -207,7 +209,7 @@ def main():
     # the same step with every launch scheduled from its own pilot launch (no costs carried over from the
     # previous frame), for comparison: what a frame of a new view costs
     pilot_ms = None
-    if nfl == 1 and not sharded:
+    if nfl == 1 and not sharded and not args.no_pilot_comparison:
         ctx.set_schedule_reuse(False)
         step()
         barrier()
@@ -260,10 +262,10 @@ def main():
             "roofline": {
                 "bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4),
-                # HBM bytes of the full (non-pilot) launch from rocprofv3 PMC passes (profiles/r1/final_headline_summary.txt and
-                # the per-dispatch values behind it): WRITE_SIZE 11.1 MB + 2 x FETCH_SIZE 3.65 MB (gfx950 tallies wide reads at
-                # half; an upper bound here); algorithmic bytes are 11.06 MB image + 0.92 MB seeds + 0.06 MB schedule
-                "traffic": 18.4e6 if args.config == "readme" else None, "traffic_unit": "bytes/launch (PMC, profiled run)",
+                # HBM bytes of a full launch from rocprofv3 PMC passes (profiles/r1/final_headline_summary.txt, largest
+                # dispatch): WRITE_SIZE 14.4 MB + 2 x FETCH_SIZE 3.67 MB (gfx950 tallies wide reads at half; an upper
+                # bound here); algorithmic bytes are 11.06 MB image + 3.69 MB recorded costs + 0.92 MB seeds + 0.06 MB schedule
+                "traffic": 21.8e6 if args.config == "readme" else None, "traffic_unit": "bytes/launch (PMC, profiled run)",
                 "flops_per_launch": flops, "flop_per_path": round(flops / launch_paths, 2),
                 "note": "peak is the packed-FMA FP32 vector rate; results are bit-exact with a non-contracting IEEE build, so "
                         "counted FLOPs issue as separate mul/add (measured ceiling 0.87 G wave-inst/s/SIMD = 57 TFLOP/s)",

@@ -10,8 +10,9 @@ def find(pattern):
 for f in find("stats/**/*kernel_stats.csv"):
     print("== kernel stats (%s)" % os.path.relpath(f, out))
     for row in csv.DictReader(open(f)):
-        print("  %-60s calls %5s  avg %12.1f ns  total %14s ns  %6s%%" % (
-            row["Name"][:60], row["Calls"], float(row["AverageNs"]), row["TotalDurationNs"], row["Percentage"]))
+        print("  %-60s calls %5s  avg %12.1f ns  min %12s  max %12s  total %14s ns  %6s%%" % (
+            row["Name"][:60], row["Calls"], float(row["AverageNs"]), row.get("MinNs", "-"), row.get("MaxNs", "-"),
+            row["TotalDurationNs"], row["Percentage"]))
 
 def pmc(dirname):
     acc = defaultdict(lambda: defaultdict(list))
@@ -19,6 +20,14 @@ def pmc(dirname):
         for row in csv.DictReader(open(f)):
             acc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
     return acc
+
+# per-dispatch durations of the render kernel (the first frame of a view is preceded by a short pilot launch)
+for f in find("stats/**/*kernel_trace.csv"):
+    durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(f)) if "k_render<false" in r["Kernel_Name"]]
+    if durs:
+        full = [d for d in durs if d > 0.5 * max(durs)]
+        print("== k_render<false,.> dispatches: %d, of which full launches %d: mean %.1f ns (min %d, max %d); others (pilot): %s" % (
+            len(durs), len(full), sum(full) / len(full), min(full), max(full), [d for d in durs if d <= 0.5 * max(durs)]))
 
 for d in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write", "pmc_tcp"):
     acc = pmc(d)
