@@ -424,3 +424,54 @@ def test_headline_config_full_size(gpu_ctx):
     got = gpu_ctx.render_block(strip)
     want = O.render_block(strip, seeds[: 64 * 8])
     assert np.array_equal(bits(got), bits(want))
+
+
+def test_uhd_config_full_resolution_shards(gpu_ctx):
+    """BASELINE configs[3] geometry (3840x2160, 4 blocks of 1920x1080) at 8 samples per seed shard:
+    device-side accumulation of shards == sum of the shards rendered one by one, every launch after
+    the first scheduled from recorded costs; a strip of shard 1 against the oracle, bit for bit."""
+    scene, cam = pkg.scene_readme(), pkg.camera_readme(3840, 8, 50)
+    bw, bh = pkg.set_blocks(cam, 4)
+    assert (cam.width, cam.height, bw, bh) == (3840, 2160, 1920, 1080)
+    gpu_ctx.upload_scene(scene)
+    shards = [pkg.make_seeds(bw * bh, 0x5EED, shard=v) for v in range(3)]
+    acc = np.zeros((cam.height, cam.width, 3), dtype=np.float32)
+    parts = []
+    for s in shards:
+        gpu_ctx.upload_seeds(s)
+        parts.append(gpu_ctx.render_frame(cam, pkg.OUT_SUM))
+        gpu_ctx.render_frame(cam, pkg.OUT_ACCUMULATE, into=acc)
+    assert np.array_equal(bits(acc), bits((parts[0] + parts[1]) + parts[2]))
+    assert np.isfinite(acc).all() and acc.min() >= 0.0 and acc.max() <= 3 * cam.samplesPerPixel
+    O = orc.Oracle(scene)
+    strip = cam.copy()
+    strip.blockSize = pkg.vec3(64, 8, 0)
+    strip.blockOffset = pkg.vec3(31, 140, 0)
+    gpu_ctx.upload_seeds(shards[1][: 64 * 8])
+    got = gpu_ctx.render_block(strip)
+    assert np.array_equal(bits(got), bits(O.render_block(strip, shards[1][: 64 * 8])))
+
+
+def test_stress_config_full_resolution(gpu_ctx):
+    """BASELINE configs[4] scene (500 spheres + 100352 triangles in 256 boxes) at 3840x2160, 2 spp:
+    the three mesh modes give the same image bit for bit (the loop mode is the reference's own
+    sphere and triangle loops), primary ids equal the oracle's on a strip."""
+    scene, cam = pkg.scene_stress(500, 224, 224, 16, 16), pkg.camera_stress(3840, 2, 50)
+    seeds = _setup(gpu_ctx, scene, cam, 4, 77)
+    images = {}
+    for mode in (pkg.MESH_BVH, pkg.MESH_BVH_STRICT, pkg.MESH_LOOP):
+        gpu_ctx.set_mesh_mode(mode)
+        images[mode] = gpu_ctx.render_frame(cam)
+    gpu_ctx.set_mesh_mode(pkg.MESH_BVH)
+    assert np.array_equal(bits(images[pkg.MESH_BVH_STRICT]), bits(images[pkg.MESH_LOOP]))
+    assert np.array_equal(bits(images[pkg.MESH_BVH]), bits(images[pkg.MESH_LOOP]))
+    ids = gpu_ctx.primary_ids(cam)
+    assert ids.min() >= -1 and ids.max() < scene.S + scene.T
+    # oracle on a strip of one block: image and primary ids
+    O = orc.Oracle(scene)
+    strip = cam.copy()
+    strip.blockSize = pkg.vec3(64, 8, 0)
+    strip.blockOffset = pkg.vec3(30, 100, 0)
+    gpu_ctx.upload_seeds(seeds[: 64 * 8])
+    got = gpu_ctx.render_block(strip)
+    assert np.array_equal(bits(got), bits(O.render_block(strip, seeds[: 64 * 8])))
