@@ -194,8 +194,8 @@ int timed_launch(wbrt_context *ctx, const RenderParams &p, hipStream_t stream)
 		key.scene_generation = ctx->scene_generation;
 		key.walks = p.sc.bvh_nodes != nullptr;
 		int cost_spp = ctx->pilot_spp;
-		if (ctx->reuse_costs && ctx->recorded_spp > 0 && std::memcmp(&key, &ctx->recorded_view, sizeof key) == 0)
-			cost_spp = ctx->recorded_spp;
+		const bool recorded = ctx->reuse_costs && ctx->recorded_spp > 0 && std::memcmp(&key, &ctx->recorded_view, sizeof key) == 0;
+		if (recorded) cost_spp = ctx->recorded_spp;
 		else
 		{
 			RenderParams pilot = p;
@@ -204,7 +204,7 @@ int timed_launch(wbrt_context *ctx, const RenderParams &p, hipStream_t stream)
 			pilot.out = nullptr;
 			HIP_TRY(wbrt_launch_render(pilot, stream));
 		}
-		HIP_TRY(wbrt_launch_cost_sort((const int *)ctx->costs.p, key.walks ? (const int *)ctx->costs.p + total : nullptr, (int)total, cost_spp, (int *)ctx->tile_costs.p,
+		HIP_TRY(wbrt_launch_cost_sort((const int *)ctx->costs.p, key.walks ? (const int *)ctx->costs.p + total : nullptr, (int)total, cost_spp, recorded ? 1 : 0, (int *)ctx->tile_costs.p,
 		                              (unsigned *)ctx->hist.p, (int *)ctx->order.p, stream));
 		q.order = (const int *)ctx->order.p;
 		if (ctx->reuse_costs)

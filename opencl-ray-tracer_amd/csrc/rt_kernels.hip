@@ -1363,11 +1363,12 @@ __global__ void k_math_probe(int op, const float *a, const float *b, float *out,
 	out[i] = r;
 }
 
-// Cost of a wave's 64 work indices, scaled into 0..255: the sum of their pilot iteration counts
-// plus 64 x the largest of them.  A wave lasts as long as its LONGEST pixel stream; tiles with a
-// few long streams among cheap ones (an object's edge against the sky) have a small sum, and
+// Cost of a wave's 64 work indices, scaled into 0..255: the sum of their iteration counts
+// plus 192 x the largest of them when the counts are a previous launch's exact ones (64 x: 1.3 % slower
+// frame, 448 x: 0.7 % slower), plus 64 x the largest for the noisier counts of a pilot launch.  A wave lasts as
+// long as its LONGEST pixel stream; tiles with a few long streams among cheap ones (an object's edge against the sky) have a small sum, and
 // ranked by the sum alone they started late and were the last to finish (weights 16..512 tried).
-__global__ void k_tile_cost(const int *costs, const int *walk, int n, int n_tiles, int shift, int *tile_costs)
+__global__ void k_tile_cost(const int *costs, const int *walk, int n, int n_tiles, int shift, int exact, int *tile_costs)
 {
 	const int tile = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
 	const int i = tile * 64 + (threadIdx.x & 63);
@@ -1380,14 +1381,8 @@ __global__ void k_tile_cost(const int *costs, const int *walk, int n, int n_tile
 		mx = other > mx ? other : mx;
 	}
 	// mesh scenes, where the walk is shared by the wave: sum + 3 per round of the walk (measured best)
-	if ((threadIdx.x & 63) == 0 && tile < n_tiles) 
-#if WBRT_TILE_RANK == 1
-		tile_costs[tile] = walk ? (c + 3 * walk[tile]) >> shift : (64 * mx) >> shift;
-#elif WBRT_TILE_RANK == 2
-		tile_costs[tile] = walk ? (c + 3 * walk[tile]) >> shift : (c + 192 * mx) >> (shift + 2);
-#else
-		tile_costs[tile] = walk ? (c + 3 * walk[tile]) >> shift : (c + 64 * mx) >> (shift + 1);
-#endif
+	if ((threadIdx.x & 63) == 0 && tile < n_tiles)
+		tile_costs[tile] = walk ? (c + 3 * walk[tile]) >> shift : exact ? (c + 192 * mx) >> (shift + 2) : (c + 64 * mx) >> (shift + 1);
 }
 
 // Counting sort of indices by cost, descending (256 buckets).
@@ -1408,10 +1403,24 @@ __global__ void k_cost_scan(unsigned *hist) // one thread: bucket 255 first
 	for (int b = 255; b >= 0; --b) { unsigned c = hist[b]; hist[b] = run; run += c; }
 }
 
+// Each block ranks a contiguous chunk in LDS and reserves one range per bucket in the global offsets.
 __global__ void k_cost_scatter(const int *costs, int n, unsigned *offsets, int *order)
 {
-	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-		order[atomicAdd(&offsets[min(costs[i], 255)], 1u)] = i;
+	__shared__ unsigned count[256], first[256];
+	const int per = (n + gridDim.x - 1) / gridDim.x;
+	const int begin = blockIdx.x * per, end = min(n, begin + per);
+	count[threadIdx.x] = 0;
+	__syncthreads();
+	for (int i = begin + threadIdx.x; i < end; i += blockDim.x) atomicAdd(&count[min(costs[i], 255)], 1u);
+	__syncthreads();
+	first[threadIdx.x] = count[threadIdx.x] ? atomicAdd(&offsets[threadIdx.x], count[threadIdx.x]) : 0u;
+	count[threadIdx.x] = 0;
+	__syncthreads();
+	for (int i = begin + threadIdx.x; i < end; i += blockDim.x)
+	{
+		const int b = min(costs[i], 255);
+		order[first[b] + atomicAdd(&count[b], 1u)] = i;
+	}
 }
 
 inline unsigned grid_for(const RenderParams &p, int block)
@@ -1438,14 +1447,14 @@ hipError_t wbrt_launch_count(const RenderParams &p, hipStream_t stream)
 	return hipGetLastError();
 }
 
-hipError_t wbrt_launch_cost_sort(const int *costs, const int *walk, int n, int pilot_spp, int *tile_costs, unsigned *hist, int *order, hipStream_t stream)
+hipError_t wbrt_launch_cost_sort(const int *costs, const int *walk, int n, int pilot_spp, int exact, int *tile_costs, unsigned *hist, int *order, hipStream_t stream)
 {
 	const int n_tiles = (n + 63) / 64;
 	int shift = 0; // a tile whose 64 streams average 16 segments per sample lands in the last bucket
 	while (((64 * 16 * pilot_spp) >> shift) > 255) ++shift;
 	hipError_t e = hipMemsetAsync(hist, 0, 256 * sizeof(unsigned), stream);
 	if (e != hipSuccess) return e;
-	hipLaunchKernelGGL(k_tile_cost, dim3((n_tiles + 3) / 4), dim3(256), 0, stream, costs, walk, n, n_tiles, shift, tile_costs);
+	hipLaunchKernelGGL(k_tile_cost, dim3((n_tiles + 3) / 4), dim3(256), 0, stream, costs, walk, n, n_tiles, shift, exact, tile_costs);
 	hipLaunchKernelGGL(k_cost_hist, dim3(64), dim3(256), 0, stream, (const int *)tile_costs, n_tiles, hist);
 	hipLaunchKernelGGL(k_cost_scan, dim3(1), dim3(1), 0, stream, hist);
 	hipLaunchKernelGGL(k_cost_scatter, dim3(64), dim3(256), 0, stream, (const int *)tile_costs, n_tiles, hist, order);
