@@ -276,6 +276,11 @@ def main():
             # the FLOP count prices every triangle test the reference's loop performs; the hierarchy walk
             # skips almost all of them, so this is a reference-equivalent work rate, not a hardware fraction
             result["roofline"]["frac"] = None
+            if args.config == "mesh":
+                # profiles/r1/final_mesh_bvh_summary.txt, largest dispatch: WRITE_SIZE 33.7 MB (image 24.9 MB + recorded costs
+                # 8.3 MB) + 2 x FETCH_SIZE 11.6 MB; the mesh (0.7 MB of triangles, 0.3 MB of nodes) stays in L2
+                result["roofline"]["traffic"] = 56.9e6
+                result["roofline"]["hbm_gb_per_s"] = round(56.9e6 / (k_ms * 1e-3) / 1e9, 2)
             result["roofline"]["note"] = ("reference-equivalent rate: FLOPs are those of the reference's per-box triangle loop "
                                           "(every triangle of a hit box tested); the kernel walks a hierarchy instead and executes far fewer")
         if sharded:
