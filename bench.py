@@ -220,6 +220,21 @@ def main():
         pilot_ms = (time.perf_counter() - t1) / 5 * 1e3
         ctx.set_schedule_reuse(True)
 
+    # mesh configuration: the same step in the mesh mode whose result is proven equal to the reference's
+    # triangle loop (the default mode's is equal in every comparison made so far, see include/ocl_rt_amd.h)
+    strict_ms = None
+    if args.config == "mesh" and nfl == 1:
+        ctx.set_mesh_mode(pkg.MESH_BVH_STRICT)
+        step()
+        step()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            step()
+        barrier()
+        strict_ms = (time.perf_counter() - t1) / 3 * 1e3
+        ctx.set_mesh_mode(pkg.MESH_BVH)
+
     if args.config == "uhd":
         paths_per_step = cam.width * cam.height * spp * shards
     elif args.config == "stress":
@@ -271,6 +286,9 @@ def main():
                         "counted FLOPs issue as separate mul/add (measured ceiling 0.87 G wave-inst/s/SIMD = 57 TFLOP/s)",
             },
         }
+        if strict_ms is not None:
+            result["config"]["mesh_mode"] = "WBRT_MESH_BVH (default)"
+            result["config"]["ms_per_step_in_WBRT_MESH_BVH_STRICT"] = round(strict_ms, 3)
         if args.config in ("mesh", "stress"):
             result["config"].pop("readme_published_gpu_frame_s", None)
             # the FLOP count prices every triangle test the reference's loop performs; the hierarchy walk
