@@ -475,3 +475,77 @@ def test_stress_config_full_resolution(gpu_ctx):
     gpu_ctx.upload_seeds(seeds[: 64 * 8])
     got = gpu_ctx.render_block(strip)
     assert np.array_equal(bits(got), bits(O.render_block(strip, seeds[: 64 * 8])))
+
+
+def _spheres(items):
+    s = (pkg.Sphere * len(items))()
+    for i, (c, r, mat) in enumerate(items):
+        s[i].center = pkg.vec3(*c)
+        s[i].radius = r
+        s[i].material = mat
+    return s
+
+
+@pytest.mark.parametrize("name", ["ties", "inside", "extremes", "huge_coordinates", "seventeen"])
+def test_sphere_scan_on_adversarial_scenes(gpu_ctx, name):
+    """Scenes built to sit on the decisions of the sphere scan: equal roots (the later sphere wins), a camera
+    inside spheres (second roots), tangent and concentric spheres, tiny and huge radii, coordinates outside the
+    range the margin-checked scan accepts (exact loop), and a table larger than the LDS copy."""
+    lam = pkg.material((0.7, 0.6, 0.5), type=0)
+    metal = pkg.material((0.8, 0.8, 0.9), fuzz=0.3, type=1)
+    mirror = pkg.material((0.9, 0.9, 0.9), fuzz=0.0, type=1)
+    glass = pkg.material((1.0, 1.0, 1.0), ior=1.5, type=2)
+    light = pkg.material((1.0, 0.9, 0.8), type=3)
+    ground = ((0.0, -100.5, -1.0), 100.0, lam)
+    if name == "ties":
+        items = [ground, ((0.0, 0.0, -1.0), 0.5, lam), ((0.0, 0.0, -1.0), 0.5, metal),   # identical spheres
+                 ((1.0, 0.0, -1.0), 0.5, mirror), ((2.0, 0.0, -1.0), 0.5, lam),            # tangent neighbours
+                 ((-1.2, 0.0, -1.0), 0.5, glass), ((-1.2, 0.0, -1.0), 0.25, light)]        # concentric
+    elif name == "inside":
+        items = [((0.0, 0.0, 0.0), 3.0, lam), ((0.0, 0.0, 0.0), 5.0, light), ((0.5, 0.0, -1.0), 0.4, glass),
+                 ((-0.5, 0.0, -1.0), 0.4, metal)]
+    elif name == "extremes":
+        items = [((0.0, -1e7 - 0.5, -1.0), 1e7, lam), ((0.0, 0.0, -1.0), 0.5, metal), ((0.6, -0.4999, -0.8), 1e-4, light),
+                 ((0.0, 0.0, -1.0), 0.0, lam), ((-0.7, -0.2, -0.9), 0.3, glass), ((0.0, 3.0e4, -1.0), 2.9e4, light)]
+    elif name == "huge_coordinates":
+        items = [ground, ((0.0, 0.0, -1.0), 0.5, lam), ((3e9, 1e9, -2e9), 1e9, metal), ((0.0, 2e8, 0.0), 1.9e8, light)]
+    else:
+        items = [ground] + [((-2.0 + 0.25 * i, 0.1 * (i % 3), -1.0 - 0.1 * (i % 4)), 0.12 + 0.01 * i, (lam, metal, glass, mirror)[i % 4])
+                            for i in range(16)]
+    scene = pkg.Scene(spheres=_spheres(items))
+    cam = pkg.camera_readme(160, 12, 50)
+    if name == "inside":
+        cam = pkg.calculate_camera((0.0, 0.2, 1.0), (0.0, 0.0, -1.0), (0.0, 1.0, 0.0), 70.0, 1.7777777, 1.5, 2.0, 160, 90, 12, 50)
+    seeds = _setup(gpu_ctx, scene, cam, 4, 2025)
+    O = orc.Oracle(scene)
+    want, oc = O.render_frame(cam, seeds, counters=True)
+    got = gpu_ctx.render_frame(cam)
+    assert np.array_equal(bits(got), bits(want))
+    assert np.array_equal(gpu_ctx.primary_ids(cam), O.primary_ids(cam, seeds))
+    gc = gpu_ctx.count_events(cam)
+    assert gc == dict(zip(pkg.COUNTER_NAMES, map(int, oc)))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_sphere_scenes(gpu_ctx, seed):
+    """Random overlapping spheres of all four material types, random cameras (half of them with defocus):
+    image and primary ids against the oracle, bit for bit."""
+    rs = np.random.RandomState(1000 + seed)
+    n = int(rs.randint(1, 21))
+    items = []
+    for i in range(n):
+        kind = int(rs.randint(0, 4))
+        mat = pkg.material(tuple(rs.uniform(0.1, 1.0, 3)), fuzz=float(rs.choice([0.0, rs.uniform(0, 0.6)])),
+                           ior=float(rs.uniform(1.1, 2.0)), type=kind)
+        radius = float(10 ** rs.uniform(-1.5, 0.3)) if i else float(10 ** rs.uniform(0.5, 2.5))
+        centre = rs.uniform(-2.0, 2.0, 3) if i else np.array([0.0, -radius - 0.5, -1.0])
+        items.append((tuple(float(x) for x in centre), radius, mat))
+    scene = pkg.Scene(spheres=_spheres(items))
+    look_from = tuple(float(x) for x in rs.uniform(-3.0, 3.0, 3))
+    aperture = float(rs.choice([0.0, rs.uniform(0.5, 4.0)]))
+    cam = pkg.calculate_camera(look_from, (0.0, 0.0, -1.0), (0.0, 1.0, 0.0), float(rs.uniform(30, 100)), 1.7777777,
+                               float(rs.uniform(1.0, 4.0)), aperture, 96, 54, 6, int(rs.choice([1, 5, 50])))
+    seeds = _setup(gpu_ctx, scene, cam, int(rs.choice([1, 4])), 3000 + seed)
+    O = orc.Oracle(scene)
+    assert np.array_equal(bits(gpu_ctx.render_frame(cam)), bits(O.render_frame(cam, seeds)))
+    assert np.array_equal(gpu_ctx.primary_ids(cam), O.primary_ids(cam, seeds))
