@@ -549,3 +549,47 @@ def test_random_sphere_scenes(gpu_ctx, seed):
     O = orc.Oracle(scene)
     assert np.array_equal(bits(gpu_ctx.render_frame(cam)), bits(O.render_frame(cam, seeds)))
     assert np.array_equal(gpu_ctx.primary_ids(cam), O.primary_ids(cam, seeds))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_mesh_scenes(gpu_ctx, seed):
+    """Random triangle soups (sizes over three decades, sliver triangles among them) in 1-5 bounding boxes plus
+    random spheres: the three mesh modes agree bit for bit and the loop mode equals the oracle."""
+    rs = np.random.RandomState(500 + seed)
+    n = int(rs.choice([60, 300, 1500]))
+    centers = rs.uniform([-1.5, -0.5, -2.5], [1.5, 1.0, -0.5], (n, 3))
+    size = 10 ** rs.uniform(-2.5, -0.3, (n, 1, 1))
+    soup = centers[:, None, :] + rs.uniform(-1, 1, (n, 3, 3)) * size
+    sliver = rs.uniform(size=n) < 0.1
+    soup[sliver, 2] = soup[sliver, 0] + (soup[sliver, 1] - soup[sliver, 0]) * 0.5 + rs.uniform(-1e-4, 1e-4, (int(sliver.sum()), 3))
+    soup = soup.astype(np.float32).reshape(-1, 9)
+    tris, mn, mx = triangles_from_soup(soup, (1, 1, 1), (0, 0, 0), pkg.material((0.7, 0.7, 0.7), 0.0, 0.0, pkg.LAMBERTIAN), 0)
+    arr = np.frombuffer(tris, dtype=np.float32).reshape(n, 16)
+    arr[:, 9:12] = rs.uniform(0.2, 1.0, (n, 3))
+    arr[:, 12] = np.where(rs.uniform(size=n) < 0.5, 0.0, 0.4)
+    arr[:, 13] = 1.5
+    arr.view(np.int32)[:, 14] = rs.randint(0, 4, n)
+    nb = int(rs.randint(1, 6))
+    box_of = rs.randint(0, nb, n).astype(np.int32)
+    arr.view(np.int32)[:, 15] = box_of
+    boxes = (pkg.BoundingBox * nb)()
+    pts = soup.reshape(n, 3, 3)
+    for b in range(nb):
+        sel = pts[box_of == b].reshape(-1, 3)
+        lo, hi = (sel.min(0), sel.max(0)) if len(sel) else (np.zeros(3), np.zeros(3))
+        boxes[b] = pkg.BoundingBox(b, pkg.vec3(*[float(x) for x in lo]), pkg.vec3(*[float(x) for x in hi]))
+    scene = pkg.Scene(spheres=pkg.scene_main_cpp().spheres, triangles=tris, boxes=boxes)
+    cam = pkg.camera_main_cpp(128, 4, int(rs.choice([3, 50])))
+    seeds = _setup(gpu_ctx, scene, cam, 4, 600 + seed)
+    try:
+        images = {}
+        for mode in (pkg.MESH_LOOP, pkg.MESH_BVH_STRICT, pkg.MESH_BVH):
+            gpu_ctx.set_mesh_mode(mode)
+            images[mode] = gpu_ctx.render_frame(cam)
+    finally:
+        gpu_ctx.set_mesh_mode(pkg.MESH_BVH)
+    assert np.array_equal(bits(images[pkg.MESH_BVH_STRICT]), bits(images[pkg.MESH_LOOP]))
+    assert np.array_equal(bits(images[pkg.MESH_BVH]), bits(images[pkg.MESH_LOOP]))
+    O = orc.Oracle(scene)
+    assert np.array_equal(bits(images[pkg.MESH_LOOP]), bits(O.render_frame(cam, seeds)))
+    assert np.array_equal(gpu_ctx.primary_ids(cam), O.primary_ids(cam, seeds))
