@@ -16,8 +16,9 @@
 //   * mesh scenes and scenes with many spheres: hierarchies built on upload, walked by the
 //     whole wave with work handed between lanes (triangles_steal), hits merged by a 64-bit
 //     atomic min whose key order is the reference's tie rule;
-//   * waves are launched costliest first, from a pilot launch with a few samples per pixel
-//     (a frame lasts as long as its longest pixel stream).
+//   * waves are launched costliest first; the costs are the ray-segment counts the previous launch of
+//     the same view recorded, or those of a pilot launch with a few samples per pixel (a frame lasts
+//     as long as its longest pixel stream).
 #include "rt_device.h"
 
 #include <math.h>
