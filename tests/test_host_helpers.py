@@ -268,3 +268,11 @@ def test_exr_writer_round_trip(tmp_path):
         out[h - 1 - y, :, 2], out[h - 1 - y, :, 1], out[h - 1 - y, :, 0] = planes[0], planes[1], planes[2]
     assert offsets[-1] + 8 + w * 12 == len(b)
     assert np.array_equal(out.view(np.uint32), img.view(np.uint32))
+
+
+def test_setters_reject_a_null_context():
+    """Entry points that only change settings report an error for a null context without touching a GPU."""
+    lib = pkg.lib()
+    for name in ("wbrt_set_schedule_reuse", "wbrt_set_mesh_mode", "wbrt_set_timing"):
+        assert getattr(lib, name)(None, 1) < 0
+        assert lib.wbrt_last_error()
