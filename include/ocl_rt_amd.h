@@ -141,7 +141,9 @@ int wbrt_synchronize(wbrt_context *ctx);
  *                         within about half a degree of a triangle's plane that passes that
  *                         triangle at more than the margin: there the reference's own
  *                         accept/reject decision is rounding noise.
- * In both BVH modes scenes with 48 or more spheres also walk a hierarchy over the spheres
+ * In both BVH modes scenes with 48 or more bounding boxes find the boxes a ray enters through a
+ * hierarchy over the boxes (conservative above, the reference's slab test gpu_kernel.cl:534-555 at
+ * the leaves: the same boxes as its loop), and scenes with 48 or more spheres also walk a hierarchy over the spheres
  * (margins proven from the reference's float sphere test: same result as its loop over all
  * spheres, gpu_kernel.cl:361-371); WBRT_MESH_LOOP loops over all spheres as well.  In strict
  * mode meshes of at most 4096 triangles use the loop.

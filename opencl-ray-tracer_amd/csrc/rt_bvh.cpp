@@ -297,3 +297,92 @@ extern "C" int wbrt_bvh_build_(const float *tri_geom, const int *ranges, int B, 
 	if (depth_out) *depth_out = bvh.depth;
 	return (int)bvh.nodes.size();
 }
+
+
+// ------------------------------------------------------------------ hierarchy over the BOXES
+// Scenes with many bounding boxes: the reference tests every box for every ray segment
+// (gpu_kernel.cl:374-376).  A balanced binary tree over the boxes' stated bounds lets a ray skip
+// groups of boxes its slab test would reject; the kernel widens every node per ray by more than
+// the rounding of that float test, and runs the reference's own test at the leaves.
+// Nodes: 4 float4 {lmin.xyz lmax.x | lmax.yz rmin.xy | rmin.z rmax.xyz | left right - -}; a child
+// reference >= 0 names a node, < 0 names a leaf: ~ref = rank of the box in left-to-right order.
+// Boxes without triangles are left out.  Returns false (no tree) when a box has bounds that are not
+// finite or not ordered, or when fewer than two boxes hold triangles.
+namespace {
+
+struct BoxItem { float mn[3], mx[3]; int index; };
+
+int build_box_node(std::vector<BoxItem> &items, int first, int count, std::vector<float4> &nodes, std::vector<int> &box_of_rank,
+                   int level, int &depth)
+{
+	if (count == 1)
+	{
+		box_of_rank.push_back(items[(size_t)first].index);
+		return ~((int)box_of_rank.size() - 1);
+	}
+	depth = std::max(depth, level + 1);
+	float cmn[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, cmx[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+	for (int i = first; i < first + count; ++i)
+		for (int a = 0; a < 3; ++a)
+		{
+			const float c = 0.5f * items[(size_t)i].mn[a] + 0.5f * items[(size_t)i].mx[a];
+			cmn[a] = std::min(cmn[a], c); cmx[a] = std::max(cmx[a], c);
+		}
+	int axis = 0;
+	for (int a = 1; a < 3; ++a) if (cmx[a] - cmn[a] > cmx[axis] - cmn[axis]) axis = a;
+	const int half = count / 2;
+	std::nth_element(items.begin() + first, items.begin() + first + half, items.begin() + first + count,
+	                 [axis](const BoxItem &x, const BoxItem &y) {
+		                 const float cx = x.mn[axis] + x.mx[axis], cy = y.mn[axis] + y.mx[axis];
+		                 return cx < cy || (cx == cy && x.index < y.index);
+	                 });
+	const int self = (int)(nodes.size() / 4);
+	nodes.resize(nodes.size() + 4);
+	float b[2][6];
+	const int starts[2] = { first, first + half }, counts[2] = { half, count - half };
+	for (int k = 0; k < 2; ++k)
+	{
+		for (int a = 0; a < 3; ++a) { b[k][a] = FLT_MAX; b[k][3 + a] = -FLT_MAX; }
+		for (int i = starts[k]; i < starts[k] + counts[k]; ++i)
+			for (int a = 0; a < 3; ++a)
+			{
+				b[k][a] = std::min(b[k][a], items[(size_t)i].mn[a]);
+				b[k][3 + a] = std::max(b[k][3 + a], items[(size_t)i].mx[a]);
+			}
+	}
+	const int left = build_box_node(items, starts[0], counts[0], nodes, box_of_rank, level + 1, depth);
+	const int right = build_box_node(items, starts[1], counts[1], nodes, box_of_rank, level + 1, depth);
+	float li, ri;
+	std::memcpy(&li, &left, 4);
+	std::memcpy(&ri, &right, 4);
+	nodes[4 * (size_t)self + 0] = make_float4(b[0][0], b[0][1], b[0][2], b[0][3]);
+	nodes[4 * (size_t)self + 1] = make_float4(b[0][4], b[0][5], b[1][0], b[1][1]);
+	nodes[4 * (size_t)self + 2] = make_float4(b[1][2], b[1][3], b[1][4], b[1][5]);
+	nodes[4 * (size_t)self + 3] = make_float4(li, ri, 0.0f, 0.0f);
+	return self;
+}
+
+} // namespace
+
+bool wbrt_build_box_tree(const float4 *box_min, const float4 *box_max, const int2 *ranges, int B,
+                         std::vector<float4> &nodes, std::vector<int> &box_of_rank, int &depth)
+{
+	nodes.clear();
+	box_of_rank.clear();
+	depth = 0;
+	std::vector<BoxItem> items;
+	for (int b = 0; b < B; ++b)
+	{
+		const float mn[3] = { box_min[b].x, box_min[b].y, box_min[b].z }, mx[3] = { box_max[b].x, box_max[b].y, box_max[b].z };
+		for (int a = 0; a < 3; ++a)
+			if (!std::isfinite(mn[a]) || !std::isfinite(mx[a]) || mn[a] > mx[a] || std::fabs(mn[a]) > 1e30f || std::fabs(mx[a]) > 1e30f) return false;
+		if (ranges[b].y <= ranges[b].x) continue; // no triangles: hitting it changes nothing
+		BoxItem it;
+		for (int a = 0; a < 3; ++a) { it.mn[a] = mn[a]; it.mx[a] = mx[a]; }
+		it.index = b;
+		items.push_back(it);
+	}
+	if (items.size() < 2) return false;
+	const int root = build_box_node(items, 0, (int)items.size(), nodes, box_of_rank, 0, depth);
+	return root == 0;
+}

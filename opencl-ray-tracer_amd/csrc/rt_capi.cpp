@@ -76,6 +76,9 @@ struct wbrt_context
 	DevBuf sph_geom, sph_radius, sph_mat_a, sph_mat_b;
 	DevBuf tri_geom, tri_mat_a, tri_mat_b, tri_orig;
 	DevBuf box_min, box_max, box_range;
+	DevBuf top_nodes, top_box;    // hierarchy over the boxes (scenes with box_tree_min or more boxes)
+	int top_depth = 0;            // 0: no such hierarchy
+	int box_tree_min = 48;        // measured crossover between 36 and 64 boxes
 	DevBuf bvh_nodes[2], bvh_tris[2], bvh_roots[2]; // [0] plain surface-area trees, [1] built for the strict margins
 	const float4 *bvh_ptr[2][3] = {};
 	int bvh_depth[2] = {0, 0};
@@ -155,6 +158,13 @@ int make_params(wbrt_context *ctx, const wbrt_camera *cam, bool whole_frame, Ren
 		p.sc.bvh_tris = ctx->bvh_ptr[variant][1];
 		p.sc.bvh_roots = ctx->bvh_ptr[variant][2];
 		p.sc.bvh_box_slots = WBRT_BVH_STACK - ctx->bvh_depth[variant] + 1;
+		if (ctx->top_depth > 0)
+		{
+			// the walk over the boxes uses the top of each lane's stack while hit boxes are queued at its bottom
+			p.sc.top_nodes = (const float4 *)ctx->top_nodes.p;
+			p.sc.top_box = (const int *)ctx->top_box.p;
+			p.sc.bvh_box_slots = std::min(p.sc.bvh_box_slots, WBRT_BVH_STACK - ctx->top_depth);
+		}
 		p.sc.sph_tree = ctx->have_sphere_tree ? 1 : 0;
 	}
 	p.sc.bvh_rho = ctx->mesh_mode == WBRT_MESH_BVH ? ctx->bvh_rho : 0.0f;
@@ -247,6 +257,7 @@ int wbrt_create(int device_ordinal, wbrt_context **out)
 	// tuning knobs for experiments (not part of the ABI contract)
 	if (const char *v = std::getenv("WBRT_LPT")) ctx->lpt = std::atoi(v) != 0;
 	if (const char *v = std::getenv("WBRT_MESH_MODE")) { int m = std::atoi(v); if (m >= 0 && m <= 2) ctx->mesh_mode = m; }
+	if (const char *v = std::getenv("WBRT_BOX_TREE_MIN")) ctx->box_tree_min = std::atoi(v);
 	if (const char *v = std::getenv("WBRT_SPHERE_TREE_MIN")) ctx->sphere_tree_min = std::atoi(v);
 	if (const char *v = std::getenv("WBRT_BVH_MIN_IDLE")) ctx->bvh_steal_min_idle = std::atoi(v);
 	if (const char *v = std::getenv("WBRT_BVH_RHO")) { float r = (float)std::atof(v); if (r > 0.0f) ctx->bvh_rho = r; }
@@ -265,7 +276,7 @@ int wbrt_destroy(wbrt_context *ctx)
 	DevBuf *all[] = { &ctx->sph_geom, &ctx->sph_radius, &ctx->sph_mat_a, &ctx->sph_mat_b, &ctx->tri_geom,
 	                  &ctx->tri_mat_a, &ctx->tri_mat_b, &ctx->tri_orig, &ctx->box_min, &ctx->box_max,
 	                  &ctx->box_range, &ctx->bvh_nodes[0], &ctx->bvh_tris[0], &ctx->bvh_roots[0],
-	                  &ctx->bvh_nodes[1], &ctx->bvh_tris[1], &ctx->bvh_roots[1], &ctx->sky, &ctx->seeds, &ctx->image, &ctx->ids, &ctx->counters, &ctx->rgb8,
+	                  &ctx->bvh_nodes[1], &ctx->bvh_tris[1], &ctx->bvh_roots[1], &ctx->top_nodes, &ctx->top_box, &ctx->sky, &ctx->seeds, &ctx->image, &ctx->ids, &ctx->counters, &ctx->rgb8,
 	                  &ctx->costs, &ctx->tile_costs, &ctx->order, &ctx->hist };
 	for (DevBuf *b : all) b->release();
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -342,6 +353,18 @@ int wbrt_upload_scene(wbrt_context *ctx, const wbrt_sphere *spheres, int32_t S,
 	UP(sph_geom, geom_padded); UP(sph_radius, radius); UP(sph_mat_a, mat_a); UP(sph_mat_b, mat_b);
 	UP(tri_geom, tgeom); UP(tri_mat_a, tmat_a); UP(tri_mat_b, tmat_b); UP(tri_orig, torig);
 	UP(box_min, bmin); UP(box_max, bmax); UP(box_range, brange);
+	ctx->top_depth = 0;
+	if (B >= ctx->box_tree_min)
+	{
+		std::vector<float4> tnodes;
+		std::vector<int> trank;
+		int tdepth = 0;
+		if (wbrt_build_box_tree(bmin.data(), bmax.data(), brange.data(), B, tnodes, trank, tdepth) && tdepth + 2 <= WBRT_BVH_STACK)
+		{
+			UP(top_nodes, tnodes); UP(top_box, trank);
+			ctx->top_depth = tdepth;
+		}
+	}
 	// A hierarchy over the spheres pays off for large sphere counts; it needs finite, moderate
 	// coordinates (the kernel's margins assume no overflow in the reference's sphere test).
 	bool sphere_tree = S >= ctx->sphere_tree_min;

@@ -50,6 +50,9 @@ struct SceneDev
 	int sph_tree;             // 1: bvh_roots[B] is a hierarchy over the spheres (leaf slot: center.xyz r^2 | - | - index - -)
 	int bvh_box_slots;        // stack entries free for queued boxes: WBRT_BVH_STACK - tree depth + 1
 	int bvh_steal_min_idle;   // idle lanes of a wave needed before a hand-over round is run
+	// hierarchy over the boxes themselves (scenes with many boxes; absent: top_nodes == nullptr)
+	const float4 *top_nodes;  // 4 per node: lmin.xyz lmax.x | lmax.yz rmin.xy | rmin.z rmax.xyz | left right - -  (leaf: ~rank)
+	const int    *top_box;    // rank (left-to-right leaf order) -> box index
 	// sky: skyw*skyh texels + skyw+1 zero guard texels, 3 floats each
 	const float *sky;
 	int skyw, skyh;
@@ -102,6 +105,8 @@ struct WbrtBvh
 	int depth = 0;
 };
 void wbrt_build_bvh(const float4 *tri_geom, const int2 *ranges, int B, bool split_by_e, WbrtBvh &bvh);
+bool wbrt_build_box_tree(const float4 *box_min, const float4 *box_max, const int2 *ranges, int B,
+                         std::vector<float4> &nodes, std::vector<int> &box_of_rank, int &depth);
 void wbrt_append_sphere_tree(const float4 *sph_geom, const float *radius, int S, WbrtBvh &bvh);
 
 hipError_t wbrt_launch_render(const RenderParams &p, hipStream_t stream);

@@ -678,6 +678,7 @@ __device__ __forceinline__ int bvh_enter_box(const SceneDev &sc, int box, BvhRay
 	return r1.w < 0.0f ? BVH_NONE : __float_as_int(r0.w);
 }
 
+template <bool BOXTREE>
 __device__ __forceinline__ void triangles_steal(const SceneDev &sc, int (*stack)[WBRT_RENDER_BLOCK], StealLds &w, bool trace, bool spheres,
                                                 F3 o, F3 d, float &closest, int &id, int &rounds)
 {
@@ -704,6 +705,62 @@ __device__ __forceinline__ void triangles_steal(const SceneDev &sc, int (*stack)
 	for (;;)
 	{
 		int resume = sc.B;
+		if (BOXTREE)
+		{
+			// Many boxes: the lane's ray walks the hierarchy over the boxes (left child first, so leaves
+			// come in increasing rank; `start` and `resume` count ranks here).  A node is skipped only when
+			// the ray misses its box widened by far more than the rounding of the reference's slab test
+			// (relative 2e-7 per plane distance); at a leaf that test itself decides.  The walk's own
+			// stack is the top of the lane's column, above the queued boxes.
+			const float pad = 2e-6f * (fabsf(o.x) + fabsf(o.y) + fabsf(o.z));
+			const F3 rel = f3(2e-6f, 2e-6f, 2e-6f);
+			int tnode = trace ? 0 : BVH_NONE, tp = WBRT_BVH_STACK;
+			while (__ballot(tnode != BVH_NONE))
+			{
+				if (tnode == BVH_NONE) continue;
+				if (tnode >= 0)
+				{
+					const float4 q0 = sc.top_nodes[4 * (size_t)tnode], q1 = sc.top_nodes[4 * (size_t)tnode + 1];
+					const float4 q2 = sc.top_nodes[4 * (size_t)tnode + 2], q3 = sc.top_nodes[4 * (size_t)tnode + 3];
+					// margin of a child: pad + 2e-6 * (largest coordinate magnitude of its box)
+					const float ml = pad + rel.x * (fmaxf(fabsf(q0.x), fabsf(q0.w)) + fmaxf(fabsf(q0.y), fabsf(q1.x)) + fmaxf(fabsf(q0.z), fabsf(q1.y)));
+					const float mr = pad + rel.x * (fmaxf(fabsf(q1.z), fabsf(q2.y)) + fmaxf(fabsf(q1.w), fabsf(q2.z)) + fmaxf(fabsf(q2.x), fabsf(q2.w)));
+					float unused;
+					const bool vl = bvh_box(f3(o.x + ml, o.y + ml, o.z + ml), f3(o.x - ml, o.y - ml, o.z - ml), r.inv,
+					                        q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, INFINITY, unused);
+					const bool vr = bvh_box(f3(o.x + mr, o.y + mr, o.z + mr), f3(o.x - mr, o.y - mr, o.z - mr), r.inv,
+					                        q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, INFINITY, unused);
+					const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
+					if (vl & vr) stack[--tp][col] = right;
+					tnode = vl ? left : vr ? right : BVH_NONE;
+				}
+				else
+				{
+					const int rank = ~tnode;
+					tnode = BVH_NONE;
+					if (rank >= start)
+					{
+						const int b = sc.top_box[rank];
+						const float4 mn = sc.box_min[b], mx = sc.box_max[b];
+						float tx1 = (mn.x - o.x) * inv_d.x, tx2 = (mx.x - o.x) * inv_d.x;
+						float lo = fminf(tx1, tx2), hi = fmaxf(tx1, tx2);
+						float ty1 = (mn.y - o.y) * inv_d.y, ty2 = (mx.y - o.y) * inv_d.y;
+						lo = fmaxf(lo, fminf(ty1, ty2));
+						hi = fminf(hi, fmaxf(ty1, ty2));
+						float tz1 = (mn.z - o.z) * inv_d.z, tz2 = (mx.z - o.z) * inv_d.z;
+						lo = fmaxf(lo, fminf(tz1, tz2));
+						hi = fminf(hi, fmaxf(tz1, tz2));
+						if (hi > fmaxf(lo, 0.0f))
+						{
+							if (sp < sc.bvh_box_slots) stack[sp++][col] = BVH_BOX_TAG | b;
+							else { resume = rank; tp = WBRT_BVH_STACK; } // the rest in a further pass
+						}
+					}
+				}
+				if (tnode == BVH_NONE && tp < WBRT_BVH_STACK) tnode = stack[tp++][col];
+			}
+		}
+		else
 		for (int b = 0; b < sc.B; ++b)
 		{
 			const float4 mn = uniform_ld(sc.box_min, b), mx = uniform_ld(sc.box_max, b);
@@ -999,7 +1056,9 @@ __device__ __forceinline__ void init_lane(const RenderParams &p, Lane &L, int gi
 // cooperative triangle phase (which runs in wave-uniform control flow) until the whole wave is
 // done: what bounds a mesh frame is its longest pixel stream, and a lone live lane still gets
 // all 64 lanes of triangle throughput this way.
-template <bool STATS, bool MESH>
+// BOXTREE: the scene comes with a hierarchy over its boxes (sc.top_nodes); a build of its own, so that scenes
+// with few boxes keep the registers of the plain loop over the boxes.
+template <bool STATS, bool MESH, bool BOXTREE = false>
 __global__ __launch_bounds__(WBRT_RENDER_BLOCK) void k_render(const RenderParams p)
 {
 	__shared__ TriTiles s_tiles[MESH && STATS ? WBRT_RENDER_BLOCK / 64 : 1]; // counting build: sequential staged loop, one per wave
@@ -1090,7 +1149,7 @@ __global__ __launch_bounds__(WBRT_RENDER_BLOCK) void k_render(const RenderParams
 				// pilot launch: the rounds of the walk (the same number in every lane) join the tile's
 				// cost estimate
 				int rounds = 0;
-				triangles_steal(sc, s_stack, s_steal[0], trace, walk_spheres, L.o, L.d, t, id, rounds);
+				triangles_steal<BOXTREE>(sc, s_stack, s_steal[0], trace, walk_spheres, L.o, L.d, t, id, rounds);
 				if (p.costs || p.record) walk_cost += rounds;
 			}
 			else triangles_cooperative(sc, s_best[threadIdx.x >> 6], trace, L.o, L.d, t, id);
@@ -1435,7 +1494,8 @@ inline unsigned grid_for(const RenderParams &p, int block)
 hipError_t wbrt_launch_render(const RenderParams &p, hipStream_t stream)
 {
 	const dim3 grid(grid_for(p, WBRT_RENDER_BLOCK)), block(WBRT_RENDER_BLOCK);
-	if (p.sc.B > 0 || (p.sc.sph_tree && p.sc.bvh_nodes)) hipLaunchKernelGGL((k_render<false, true>), grid, block, 0, stream, p);
+	if (p.sc.top_nodes && p.sc.bvh_nodes) hipLaunchKernelGGL((k_render<false, true, true>), grid, block, 0, stream, p);
+	else if (p.sc.B > 0 || (p.sc.sph_tree && p.sc.bvh_nodes)) hipLaunchKernelGGL((k_render<false, true>), grid, block, 0, stream, p);
 	else hipLaunchKernelGGL((k_render<false, false>), grid, block, 0, stream, p);
 	return hipGetLastError();
 }

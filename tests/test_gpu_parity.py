@@ -593,3 +593,30 @@ def test_random_mesh_scenes(gpu_ctx, seed):
     O = orc.Oracle(scene)
     assert np.array_equal(bits(images[pkg.MESH_LOOP]), bits(O.render_frame(cam, seeds)))
     assert np.array_equal(gpu_ctx.primary_ids(cam), O.primary_ids(cam, seeds))
+
+
+@pytest.mark.parametrize("name", ["awkward", "stress36", "many_boxes"])
+def test_box_hierarchy_equals_box_loop(name, monkeypatch):
+    """The hierarchy over the bounding boxes (used from 48 boxes on, forced here from 2) queues exactly
+    the boxes the reference's slab test accepts: same image as the loop over all boxes and as the oracle."""
+    if name == "awkward":
+        scene, cam = _awkward_mesh_scene(), pkg.camera_main_cpp(192, 6, 50)
+    elif name == "stress36":
+        scene, cam = pkg.scene_stress(60, 48, 48, 6, 6), pkg.camera_stress(256, 4, 50)
+    else:
+        scene, cam = _many_boxes_scene(), pkg.camera_main_cpp(160, 4, 50)
+    images = {}
+    for tree_min in (2, 1 << 30):
+        monkeypatch.setenv("WBRT_BOX_TREE_MIN", str(tree_min))
+        ctx = pkg.Context(0)
+        try:
+            seeds = _setup(ctx, scene, cam, 4, 21)
+            for mode in (pkg.MESH_BVH, pkg.MESH_BVH_STRICT):
+                ctx.set_mesh_mode(mode)
+                images[(tree_min, mode)] = ctx.render_frame(cam)
+        finally:
+            ctx.close()
+    ref = images[(1 << 30, pkg.MESH_BVH_STRICT)]
+    for key, img in images.items():
+        assert np.array_equal(bits(img), bits(ref)), key
+    assert np.array_equal(bits(ref), bits(orc.Oracle(scene).render_frame(cam, seeds)))
