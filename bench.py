@@ -299,6 +299,12 @@ def main():
                 # 8.3 MB) + 2 x FETCH_SIZE 11.6 MB; the mesh (0.7 MB of triangles, 0.3 MB of nodes) stays in L2
                 result["roofline"]["traffic"] = 56.9e6
                 result["roofline"]["hbm_gb_per_s"] = round(56.9e6 / (k_ms * 1e-3) / 1e9, 2)
+            if args.config == "stress":
+                # profiles/r1/final_stress_summary.txt, largest dispatch (one 63-spp shard): WRITE_SIZE 133.7 MB (accumulation
+                # read-modify-write 99.5 MB + recorded costs 33 MB) + 2 x FETCH_SIZE 73.4 GB: the 100352 triangles and their
+                # hierarchies (7 MB) exceed an XCD's 4 MB L2, so node and triangle fetches go to the fabric
+                result["roofline"]["traffic"] = 146.9e9
+                result["roofline"]["hbm_gb_per_s"] = round(146.9e9 / (k_ms * 1e-3) / 1e9, 1)
             result["roofline"]["note"] = ("reference-equivalent rate: FLOPs are those of the reference's per-box triangle loop "
                                           "(every triangle of a hit box tested); the kernel walks a hierarchy instead and executes far fewer")
         if sharded:
