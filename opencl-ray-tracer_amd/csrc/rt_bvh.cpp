@@ -386,3 +386,22 @@ bool wbrt_build_box_tree(const float4 *box_min, const float4 *box_max, const int
 	const int root = build_box_node(items, 0, (int)items.size(), nodes, box_of_rank, 0, depth);
 	return root == 0;
 }
+
+// Test hook (not in the public header): the hierarchy over the boxes.  box_min/box_max: 4 floats per
+// box; ranges: first,last per box; nodes_out: 16 floats per node (nodes_cap nodes), rank_out: B ints.
+// Returns the node count (0: no tree), leaves in *leaves_out, inner levels in *depth_out.
+extern "C" int wbrt_box_tree_build_(const float *box_min, const float *box_max, const int *ranges, int B, float *nodes_out, int nodes_cap,
+                                    int *rank_out, int *leaves_out, int *depth_out)
+{
+	std::vector<float4> nodes;
+	std::vector<int> rank;
+	int depth = 0;
+	if (!wbrt_build_box_tree(reinterpret_cast<const float4 *>(box_min), reinterpret_cast<const float4 *>(box_max),
+	                         reinterpret_cast<const int2 *>(ranges), B, nodes, rank, depth)) return 0;
+	if ((int)(nodes.size() / 4) > nodes_cap || (int)rank.size() > B) return -1;
+	std::memcpy(nodes_out, nodes.data(), nodes.size() * sizeof(float4));
+	std::memcpy(rank_out, rank.data(), rank.size() * sizeof(int));
+	*leaves_out = (int)rank.size();
+	*depth_out = depth;
+	return (int)(nodes.size() / 4);
+}

@@ -111,3 +111,62 @@ def test_builder_handles_non_finite_vertices():
     nodes, tri_index, roots, depth = _build(geom, ranges)
     assert depth <= STACK
     assert sorted(tri_index[:200].tolist()) == list(range(200))
+
+
+def _box_tree(mn, mx, ranges):
+    L = pkg.lib()
+    L.wbrt_box_tree_build_.restype = C.c_int
+    B = mn.shape[0]
+    nodes = np.zeros((max(B, 1), 16), np.float32)
+    rank = np.zeros(max(B, 1), np.int32)
+    leaves, depth = C.c_int(0), C.c_int(0)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    n = L.wbrt_box_tree_build_(p(mn), p(mx), p(ranges), B, p(nodes), nodes.shape[0], p(rank), C.byref(leaves), C.byref(depth))
+    assert n >= 0
+    return nodes[:n], rank[:leaves.value], depth.value
+
+
+def test_box_tree_covers_every_box_with_triangles():
+    """Hierarchy over the boxes: every box that holds triangles is exactly one leaf, leaves are numbered left to
+    right, each child box contains the stated bounds of the boxes below it, the tree is balanced."""
+    rs = np.random.RandomState(5)
+    for B in (2, 3, 48, 257):
+        mn = np.zeros((B, 4), np.float32); mx = np.zeros((B, 4), np.float32)
+        lo = rs.uniform(-10, 10, (B, 3)); mn[:, :3] = lo; mx[:, :3] = lo + rs.uniform(0.0, 3.0, (B, 3))
+        counts = rs.randint(0, 5, B); counts[:2] = 1
+        first = np.concatenate([[0], np.cumsum(counts)])
+        ranges = np.stack([first[:-1], first[1:]], axis=1).astype(np.int32)
+        nodes, rank, depth = _box_tree(mn, mx, ranges)
+        want = np.flatnonzero(counts > 0)
+        assert sorted(rank.tolist()) == want.tolist()
+        assert depth <= int(np.ceil(np.log2(len(want)))) + 1 and depth + 2 <= STACK
+        seen = []
+
+        def walk(ref, bmn, bmx):
+            if ref < 0:
+                b = rank[~ref]
+                seen.append(~ref)
+                assert (mn[b, :3] >= bmn).all() and (mx[b, :3] <= bmx).all()
+                return
+            q = nodes[ref]
+            l, r = q[12:14].view(np.int32)
+            lmn, lmx, rmn, rmx = q[0:3], q[3:6], q[6:9], q[9:12]
+            if bmn is not None:
+                assert (lmn >= bmn).all() and (lmx <= bmx).all() and (rmn >= bmn).all() and (rmx <= bmx).all()
+            walk(int(l), lmn, lmx)
+            walk(int(r), rmn, rmx)
+
+        walk(0, None, None)
+        assert seen == list(range(len(want)))  # left child first visits the leaves in rank order
+
+
+def test_box_tree_refuses_unusable_boxes():
+    mn = np.zeros((4, 4), np.float32); mx = np.ones((4, 4), np.float32)
+    ranges = np.array([[0, 1], [1, 2], [2, 3], [3, 4]], np.int32)
+    assert _box_tree(mn, mx, ranges)[0].shape[0] == 3
+    bad = mx.copy(); bad[2, 1] = np.nan
+    assert _box_tree(mn, bad, ranges)[0].shape[0] == 0           # non-finite bound
+    inv = mx.copy(); inv[1, 0] = -1.0
+    assert _box_tree(mn, inv, ranges)[0].shape[0] == 0           # min > max
+    one = np.array([[0, 1], [1, 1], [1, 1], [1, 1]], np.int32)
+    assert _box_tree(mn, mx, one)[0].shape[0] == 0               # a single box with triangles
