@@ -1296,15 +1296,14 @@ __global__ __launch_bounds__(WBRT_RENDER_BLOCK) void k_render(const RenderParams
 		if (outcome != 0)
 		{
 			// gpu_kernel.cl:632-644: clamp, NaN -> running sum, accumulate
-			if (col.x > 1.0f) col.x = 1.0f;
-			if (col.y > 1.0f) col.y = 1.0f;
-			if (col.z > 1.0f) col.z = 1.0f;
-			if (col.x < 0.0f) col.x = 0.0f;
-			if (col.y < 0.0f) col.y = 0.0f;
-			if (col.z < 0.0f) col.z = 0.0f;
-			if (col.x != col.x) col.x = L.sum.x;
-			if (col.y != col.y) col.y = L.sum.y;
-			if (col.z != col.z) col.z = L.sum.z;
+			// (the median of {c, 0, 1} is the two-sided clamp for every number; a NaN, which passes both of
+			// the reference's comparisons, is replaced afterwards; a -0 may become +0, which the sum, never
+			// -0 itself, does not see)
+			const F3 raw = col;
+			col = f3(__builtin_amdgcn_fmed3f(raw.x, 0.0f, 1.0f), __builtin_amdgcn_fmed3f(raw.y, 0.0f, 1.0f), __builtin_amdgcn_fmed3f(raw.z, 0.0f, 1.0f));
+			if (raw.x != raw.x) col.x = L.sum.x;
+			if (raw.y != raw.y) col.y = L.sum.y;
+			if (raw.z != raw.z) col.z = L.sum.z;
 			L.sum = L.sum + col;
 			L.sample++;
 			if (L.sample < p.spp) camera_ray<STATS>(p, L, ctr);

@@ -486,7 +486,7 @@ def _spheres(items):
     return s
 
 
-@pytest.mark.parametrize("name", ["ties", "inside", "extremes", "huge_coordinates", "seventeen"])
+@pytest.mark.parametrize("name", ["ties", "inside", "extremes", "huge_coordinates", "seventeen", "clamp_and_nan"])
 def test_sphere_scan_on_adversarial_scenes(gpu_ctx, name):
     """Scenes built to sit on the decisions of the sphere scan: equal roots (the later sphere wins), a camera
     inside spheres (second roots), tangent and concentric spheres, tiny and huge radii, coordinates outside the
@@ -507,6 +507,11 @@ def test_sphere_scan_on_adversarial_scenes(gpu_ctx, name):
     elif name == "extremes":
         items = [((0.0, -1e7 - 0.5, -1.0), 1e7, lam), ((0.0, 0.0, -1.0), 0.5, metal), ((0.6, -0.4999, -0.8), 1e-4, light),
                  ((0.0, 0.0, -1.0), 0.0, lam), ((-0.7, -0.2, -0.9), 0.3, glass), ((0.0, 3.0e4, -1.0), 2.9e4, light)]
+    elif name == "clamp_and_nan":
+        # sample colours above 1, below 0, NaN and -0: the per-sample clamp and the NaN quirk (gpu_kernel.cl:632-642)
+        items = [ground, ((0.0, 0.0, -1.0), 0.5, pkg.material((3.0, -2.0, float("nan")), type=3)),
+                 ((1.1, 0.0, -1.0), 0.5, pkg.material((float("nan"), 0.5, 2.0), type=0)),
+                 ((-1.1, 0.0, -1.0), 0.5, pkg.material((-0.0, 1.5, float("inf")), fuzz=0.1, type=1))]
     elif name == "huge_coordinates":
         items = [ground, ((0.0, 0.0, -1.0), 0.5, lam), ((3e9, 1e9, -2e9), 1e9, metal), ((0.0, 2e8, 0.0), 1.9e8, light)]
     else:
