@@ -267,14 +267,14 @@ __device__ __forceinline__ bool sky_texel_fast(const SceneDev &sc, F3 d, int &id
 	float r = atan01(lo * __builtin_amdgcn_rcpf(hi));
 	if (az > ax) r = PI_2 - r;
 	if (d.x < 0.0f) r = PI - r;
-	if (d.z < 0.0f) r = -r;
+	r = copysignf(r, d.z); // d.z != 0 whenever the result is used
 	const float fx = __builtin_fmaf(r, 0.159154943091895346f, 0.5f) * (float)sc.skyw;
 	// elevation atan2(y, sqrt(x^2+z^2)) == asin(y/|d|)
 	const float hd = __builtin_amdgcn_sqrtf(h2);
 	hi = fmaxf(ay, hd); lo = fminf(ay, hd);
 	float e = atan01(lo * __builtin_amdgcn_rcpf(hi));
 	if (ay > hd) e = PI_2 - e;
-	if (d.y < 0.0f) e = -e;
+	e = copysignf(e, d.y); // e == 0 when d.y is a zero of either sign
 	const float fy = __builtin_fmaf(-e, 0.318309886183790691f, 0.5f) * (float)sc.skyh;
 	const float inv_cos = __builtin_amdgcn_sqrtf(l2) * __builtin_amdgcn_rcpf(hd);
 	const float bx = 1e-6f * (float)sc.skyw;
