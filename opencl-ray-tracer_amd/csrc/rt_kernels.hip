@@ -298,21 +298,21 @@ __device__ __forceinline__ bool sky_texel_fast(const SceneDev &sc, F3 d, int &id
 // Straight-line form: every sphere yields an interval [lo, hi] around the approximate numerator
 // of the root the reference would take (lo = +inf when it certainly takes none); the loop keeps the
 // smallest and second smallest lower bound.  The candidate with the smallest lower bound is the
-// reference's winner whenever its upper bound lies below every other lower bound.  A root whose
-// comparison with tMin falls inside the margin gets lo = -1 or hi = +inf, which fails that check.
+// reference's winner whenever its lower bound plus twice the largest margin of the segment lies below every
+// other lower bound.  A root whose comparison with tMin falls inside the margin gets lo = -1, which fails that check.
 // Bounds are positive floats, +inf or negative, so they are ordered as signed integers.
 // Requires |o| < 1e8, 1e-20 < a < 1e16 and sphere data below 1e8 (no overflow, no NaN in disc).
 struct SphereScan
 {
 	float a, T_lo, T_hi;
-	float bhi, bhb, bsd;
+	float m_all, bhb, bsd;
 	int min1, min2, id;
 	__device__ __forceinline__ void begin(float a_)
 	{
 		a = a_;
 		const float T = 0.001f * a;
 		T_lo = T * (1.0f - 4e-7f); T_hi = T * (1.0f + 4e-7f);
-		min1 = min2 = 0x7f800000; bhi = INFINITY; bhb = bsd = 0.0f; id = -1;
+		min1 = min2 = 0x7f800000; m_all = 0.0f; bhb = bsd = 0.0f; id = -1;
 	}
 	__device__ __forceinline__ void test(F3 o, F3 d, float gx, float gy, float gz, float gw, int i)
 	{
@@ -331,16 +331,17 @@ struct SphereScan
 		const float lo1 = n1 - m, hi1 = n1 + m, lo2 = n2 - m, hi2 = n2 + m;
 		const bool f_ok = lo1 > T_hi, f_bad = !(hi1 >= T_lo);   // first root certainly >= tMin / < tMin
 		const bool s_ok = lo2 > T_hi, s_bad = !(hi2 >= T_lo);
-		float lo = f_bad ? (s_bad ? INFINITY : lo2) : -1.0f;
+		// lower bound of the numerator of the root the reference takes: +inf when it certainly takes none,
+		// -1 (which fails the final check) when a comparison with tMin is inside the margin
+		float lo = (f_bad & s_bad) ? INFINITY : -1.0f;
+		lo = (f_bad & s_ok) ? lo2 : lo;
 		lo = f_ok ? lo1 : lo;
-		float hi = (f_bad & s_ok) ? hi2 : INFINITY;
-		hi = f_ok ? hi1 : hi;
+		m_all = fmaxf(m_all, m);                                // the largest margin of the segment (a miss: NaN, ignored)
 		const float sd = f_ok ? -disc : disc;                   // sign marks which root (both equal at 0)
 		const int ilo = __float_as_int(lo);
 		const bool less = ilo < min1;
 		min2 = min(min2, max(min1, ilo));
 		min1 = min(min1, ilo);
-		bhi = less ? hi : bhi;
 		bhb = less ? hb : bhb;
 		bsd = less ? sd : bsd;
 		id = less ? i : id;
@@ -354,7 +355,9 @@ struct SphereScan
 			const float sq = sqrtf(fabsf(bsd));
 			t_out = (__builtin_signbitf(bsd) ? (-bhb - sq) : (-bhb + sq)) / a;
 		}
-		return in_range & ((id < 0) | (bhi < __int_as_float(min2)));
+		// the winner's numerator lies in [min1, min1 + 2 margins]; every other candidate's at or above min2
+		const bool apart = min1 >= 0 && __builtin_fmaf(2.0f, m_all, __int_as_float(min1)) < __int_as_float(min2);
+		return in_range & ((id < 0) | apart);
 	}
 };
 
