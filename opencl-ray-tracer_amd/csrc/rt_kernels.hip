@@ -337,13 +337,12 @@ struct SphereScan
 		lo = (f_bad & s_ok) ? lo2 : lo;
 		lo = f_ok ? lo1 : lo;
 		m_all = fmaxf(m_all, m);                                // the largest margin of the segment (a miss: NaN, ignored)
-		const float sd = f_ok ? -disc : disc;                   // sign marks which root (both equal at 0)
 		const int ilo = __float_as_int(lo);
 		const bool less = ilo < min1;
 		min2 = min(min2, max(min1, ilo));
 		min1 = min(min1, ilo);
 		bhb = less ? hb : bhb;
-		bsd = less ? sd : bsd;
+		bsd = less ? disc : bsd;
 		id = less ? i : id;
 	}
 	__device__ __forceinline__ bool finish(bool in_range, float &t_out, int &id_out)
@@ -352,8 +351,10 @@ struct SphereScan
 		t_out = INFINITY;
 		if (id >= 0)
 		{
-			const float sq = sqrtf(fabsf(bsd));
-			t_out = (__builtin_signbitf(bsd) ? (-bhb - sq) : (-bhb + sq)) / a;
+			// the reference's own choice of root (gpu_kernel.cl:468-478), which the margins made certain
+			const float sq = sqrtf(bsd);
+			t_out = (-bhb - sq) / a;
+			if (t_out < 0.001f) t_out = (-bhb + sq) / a;
 		}
 		// the winner's numerator lies in [min1, min1 + 2 margins]; every other candidate's at or above min2
 		const bool apart = min1 >= 0 && __builtin_fmaf(2.0f, m_all, __int_as_float(min1)) < __int_as_float(min2);
