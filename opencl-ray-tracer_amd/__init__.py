@@ -161,6 +161,8 @@ def lib():
             fn.argtypes = args
         l.wbrt_math_probe_.restype = C.c_int
         l.wbrt_math_probe_.argtypes = [_P, C.c_int, _P, _P, _P, C.c_int32]
+        l.wbrt_tune_.restype = C.c_int
+        l.wbrt_tune_.argtypes = [_P, C.c_char_p, C.c_int]
         _lib = l
     return _lib
 
@@ -404,6 +406,10 @@ class Context:
     def render_frame_device(self, cam, device_ptr, out_mode=OUT_MEAN, stream=None):
         _check(lib().wbrt_render_frame_device(self._h, C.byref(cam), out_mode, C.c_void_p(device_ptr),
                                               C.c_void_p(stream) if stream else None))
+
+    def tune(self, key, value):
+        """Private test/experiment hook (wbrt_tune_): thresholds that never change a result."""
+        _check(lib().wbrt_tune_(self._h, key.encode(), int(value)))
 
     def primary_ids(self, cam):
         out = np.empty((cam.height, cam.width), dtype=np.int32)

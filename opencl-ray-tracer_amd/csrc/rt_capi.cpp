@@ -64,7 +64,7 @@ struct ViewKey
 {
 	float cam[18];
 	float aperture;
-	int dims[10];
+	int dims[11];
 	unsigned long long scene_generation;
 	int walks;
 };
@@ -97,7 +97,11 @@ struct wbrt_context
 	int sphere_tree_min = 48;  // sphere count from which the render build walks a sphere hierarchy
 	size_t n_seeds = 0;
 	bool timing = false;
-	std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> events; // pool; the first events_used pairs hold launches
+	size_t events_used = 0;
+	hipEvent_t schedule_done = nullptr; // recorded after every launch that used the context's schedule arrays
+	bool schedule_busy = false;
+	int arith_mode = 0;
 };
 
 namespace {
@@ -172,26 +176,58 @@ int make_params(wbrt_context *ctx, const wbrt_camera *cam, bool whole_frame, Ren
 	return WBRT_OK;
 }
 
-int timed_launch(wbrt_context *ctx, const RenderParams &p, hipStream_t stream)
+// Event pairs of the kernel-only timing live in a pool owned by the context: a pair is created once,
+// reused after wbrt_get_timing(reset) and destroyed with the context, whatever a launch in between returns.
+int timing_begin(wbrt_context *ctx, hipStream_t stream)
 {
-	hipEvent_t a = nullptr, b = nullptr;
-	if (ctx->timing)
+	if (ctx->events_used == ctx->events.size())
 	{
+		hipEvent_t a = nullptr, b = nullptr;
 		HIP_TRY(hipEventCreate(&a));
-		HIP_TRY(hipEventCreate(&b));
-		HIP_TRY(hipEventRecord(a, stream));
+		hipError_t e = hipEventCreate(&b);
+		if (e != hipSuccess) { (void)hipEventDestroy(a); HIP_TRY(e); }
+		ctx->events.emplace_back(a, b);
 	}
-	// Longest-first schedule (see k_render): a pilot launch with a few samples per pixel prices
-	// every pixel stream, a counting sort orders them, the real launch follows that order.
+	HIP_TRY(hipEventRecord(ctx->events[ctx->events_used].first, stream));
+	return WBRT_OK;
+}
+
+int timing_end(wbrt_context *ctx, hipStream_t stream)
+{
+	HIP_TRY(hipEventRecord(ctx->events[ctx->events_used].second, stream));
+	ctx->events_used++;
+	return WBRT_OK;
+}
+
+// One render launch, scheduled longest pixel streams first (see k_render): a pilot launch with a few
+// samples per pixel (or the counts the previous launch of the same view recorded) prices every pixel
+// stream, a counting sort orders the waves, the real launch follows that order.
+// fixed == nullptr: the schedule arrays are the context's own buffers (grown on demand) and the launch
+// records its counts for the next one.  fixed != nullptr: the arrays are given, nothing is allocated,
+// recorded or reused, and no timing events are touched.
+int scheduled_launch(wbrt_context *ctx, const RenderParams &p, hipStream_t stream, const WbrtSchedule *fixed)
+{
+	const bool timing = ctx->timing && !fixed;
+	if (timing) { int rc = timing_begin(ctx, stream); if (rc) return rc; }
 	RenderParams q = p;
 	const long long total = (long long)p.bsx * p.bsy * p.nbx * p.nby;
 	if (ctx->lpt && total >= 65536 && total % 64 == 0 && p.spp >= 8 * ctx->pilot_spp)
 	{
-		int rc = ctx->costs.reserve((size_t)(total + total / 64 + 1) * sizeof(int));
-		if (!rc) rc = ctx->order.reserve((size_t)(total / 64 + 1) * sizeof(int));
-		if (!rc) rc = ctx->tile_costs.reserve((size_t)(total / 64 + 1) * sizeof(int));
-		if (!rc) rc = ctx->hist.reserve(256 * sizeof(unsigned));
-		if (rc) return rc;
+		WbrtSchedule s;
+		if (fixed) s = *fixed;
+		else
+		{
+			int rc = ctx->costs.reserve((size_t)(total + total / 64 + 1) * sizeof(int));
+			if (!rc) rc = ctx->order.reserve((size_t)(total / 64 + 1) * sizeof(int));
+			if (!rc) rc = ctx->tile_costs.reserve((size_t)(total / 64 + 1) * sizeof(int));
+			if (!rc) rc = ctx->hist.reserve(256 * sizeof(unsigned));
+			if (rc) return rc;
+			s.costs = (int *)ctx->costs.p; s.order = (int *)ctx->order.p;
+			s.tile_costs = (int *)ctx->tile_costs.p; s.hist = (unsigned *)ctx->hist.p;
+			// the arrays are shared by every launch of this context: a launch on another stream waits until
+			// the previous launch has finished with them
+			if (ctx->schedule_busy) HIP_TRY(hipStreamWaitEvent(stream, ctx->schedule_done, 0));
+		}
 		// The full launch records the exact counts of every pixel stream; while the view (camera,
 		// tiling, depth, scene, mesh mode) stays the same they price the next launch, whatever its
 		// seeds or sample count, and no pilot launch is needed.  The schedule never changes a result.
@@ -199,38 +235,47 @@ int timed_launch(wbrt_context *ctx, const RenderParams &p, hipStream_t stream)
 		std::memset(&key, 0, sizeof key);
 		std::memcpy(key.cam, p.org, sizeof key.cam);
 		key.aperture = p.aperture;
-		const int dims[] = { p.width, p.height, p.max_depth, p.bsx, p.bsy, p.nbx, p.nby, p.off_bx, p.off_by, ctx->mesh_mode };
+		const int dims[] = { p.width, p.height, p.max_depth, p.bsx, p.bsy, p.nbx, p.nby, p.off_bx, p.off_by, ctx->mesh_mode, ctx->arith_mode };
+		static_assert(sizeof dims == sizeof key.dims, "view key");
 		std::memcpy(key.dims, dims, sizeof dims);
 		key.scene_generation = ctx->scene_generation;
 		key.walks = p.sc.bvh_nodes != nullptr;
 		int cost_spp = ctx->pilot_spp;
-		const bool recorded = ctx->reuse_costs && ctx->recorded_spp > 0 && std::memcmp(&key, &ctx->recorded_view, sizeof key) == 0;
+		const bool reuse = ctx->reuse_costs && !fixed;
+		const bool recorded = reuse && ctx->recorded_spp > 0 && std::memcmp(&key, &ctx->recorded_view, sizeof key) == 0;
 		if (recorded) cost_spp = ctx->recorded_spp;
 		else
 		{
 			RenderParams pilot = p;
 			pilot.spp = ctx->pilot_spp;
-			pilot.costs = (int *)ctx->costs.p;
+			pilot.costs = s.costs;
 			pilot.out = nullptr;
 			HIP_TRY(wbrt_launch_render(pilot, stream));
 		}
-		HIP_TRY(wbrt_launch_cost_sort((const int *)ctx->costs.p, key.walks ? (const int *)ctx->costs.p + total : nullptr, (int)total, cost_spp, recorded ? 1 : 0, (int *)ctx->tile_costs.p,
-		                              (unsigned *)ctx->hist.p, (int *)ctx->order.p, stream));
-		q.order = (const int *)ctx->order.p;
-		if (ctx->reuse_costs)
+		HIP_TRY(wbrt_launch_cost_sort(s.costs, key.walks ? s.costs + total : nullptr, (int)total, cost_spp, recorded ? 1 : 0, s.tile_costs,
+		                              s.hist, s.order, stream));
+		q.order = s.order;
+		if (reuse)
 		{
-			q.record = (int *)ctx->costs.p;
+			q.record = s.costs;
 			std::memcpy(&ctx->recorded_view, &key, sizeof key);
 			ctx->recorded_spp = p.spp;
 		}
+		HIP_TRY(wbrt_launch_render(q, stream));
+		if (!fixed)
+		{
+			HIP_TRY(hipEventRecord(ctx->schedule_done, stream));
+			ctx->schedule_busy = true;
+		}
 	}
-	HIP_TRY(wbrt_launch_render(q, stream));
-	if (ctx->timing)
-	{
-		HIP_TRY(hipEventRecord(b, stream));
-		ctx->events.emplace_back(a, b);
-	}
+	else HIP_TRY(wbrt_launch_render(q, stream));
+	if (timing) return timing_end(ctx, stream);
 	return WBRT_OK;
+}
+
+int timed_launch(wbrt_context *ctx, const RenderParams &p, hipStream_t stream)
+{
+	return scheduled_launch(ctx, p, stream, nullptr);
 }
 
 } // namespace
@@ -254,15 +299,8 @@ int wbrt_create(int device_ordinal, wbrt_context **out)
 	ctx->device = device_ordinal;
 	e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
 	if (e != hipSuccess) { delete ctx; return fail(WBRT_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorName(e)); }
-	// tuning knobs for experiments (not part of the ABI contract)
-	if (const char *v = std::getenv("WBRT_LPT")) ctx->lpt = std::atoi(v) != 0;
-	if (const char *v = std::getenv("WBRT_MESH_MODE")) { int m = std::atoi(v); if (m >= 0 && m <= 2) ctx->mesh_mode = m; }
-	if (const char *v = std::getenv("WBRT_BOX_TREE_MIN")) ctx->box_tree_min = std::atoi(v);
-	if (const char *v = std::getenv("WBRT_SPHERE_TREE_MIN")) ctx->sphere_tree_min = std::atoi(v);
-	if (const char *v = std::getenv("WBRT_BVH_MIN_IDLE")) ctx->bvh_steal_min_idle = std::atoi(v);
-	if (const char *v = std::getenv("WBRT_BVH_RHO")) { float r = (float)std::atof(v); if (r > 0.0f) ctx->bvh_rho = r; }
-	if (const char *v = std::getenv("WBRT_REUSE_COSTS")) ctx->reuse_costs = std::atoi(v) != 0;
-	if (const char *v = std::getenv("WBRT_PILOT_SPP")) ctx->pilot_spp = std::atoi(v) > 0 ? std::atoi(v) : 4;
+	e = hipEventCreateWithFlags(&ctx->schedule_done, hipEventDisableTiming);
+	if (e != hipSuccess) { (void)hipStreamDestroy(ctx->stream); delete ctx; return fail(WBRT_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorName(e)); }
 	*out = ctx;
 	return WBRT_OK;
 }
@@ -273,6 +311,7 @@ int wbrt_destroy(wbrt_context *ctx)
 	(void)hipSetDevice(ctx->device);
 	(void)hipDeviceSynchronize();
 	for (auto &ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+	if (ctx->schedule_done) (void)hipEventDestroy(ctx->schedule_done);
 	DevBuf *all[] = { &ctx->sph_geom, &ctx->sph_radius, &ctx->sph_mat_a, &ctx->sph_mat_b, &ctx->tri_geom,
 	                  &ctx->tri_mat_a, &ctx->tri_mat_b, &ctx->tri_orig, &ctx->box_min, &ctx->box_max,
 	                  &ctx->box_range, &ctx->bvh_nodes[0], &ctx->bvh_tris[0], &ctx->bvh_roots[0],
@@ -605,20 +644,16 @@ int wbrt_get_timing(wbrt_context *ctx, double *total_ms, int32_t *launches, int 
 	int rc = bind(ctx);
 	if (rc) return rc;
 	double sum = 0.0;
-	for (auto &ev : ctx->events)
+	for (size_t i = 0; i < ctx->events_used; ++i)
 	{
-		HIP_TRY(hipEventSynchronize(ev.second));
+		HIP_TRY(hipEventSynchronize(ctx->events[i].second));
 		float ms = 0.0f;
-		HIP_TRY(hipEventElapsedTime(&ms, ev.first, ev.second));
+		HIP_TRY(hipEventElapsedTime(&ms, ctx->events[i].first, ctx->events[i].second));
 		sum += ms;
 	}
 	if (total_ms) *total_ms = sum;
-	if (launches) *launches = (int32_t)ctx->events.size();
-	if (reset)
-	{
-		for (auto &ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
-		ctx->events.clear();
-	}
+	if (launches) *launches = (int32_t)ctx->events_used;
+	if (reset) ctx->events_used = 0; // the pairs stay in the pool
 	return WBRT_OK;
 }
 
@@ -633,6 +668,25 @@ int wbrt_device_info(wbrt_context *ctx, char *buf, size_t buf_len)
 	              "device %d: %s (%s), %d CUs, %d MHz, %.1f GiB, LDS/block %zu B, wave %d",
 	              ctx->device, prop.name, prop.gcnArchName, prop.multiProcessorCount, prop.clockRate / 1000,
 	              (double)prop.totalGlobalMem / (1024.0 * 1024.0 * 1024.0), prop.sharedMemPerBlock, prop.warpSize);
+	return WBRT_OK;
+}
+
+// Test and experiment hook (not in the public header): thresholds the library otherwise fixes.
+//   "lpt" 0/1 longest-first scheduling; "pilot_spp" samples of a pilot launch; "box_tree_min" /
+//   "sphere_tree_min" primitive counts from which the hierarchies over boxes / spheres are built (take
+//   effect at the next wbrt_upload_scene); "bvh_min_idle" idle lanes before a hand-over round.
+// None of them changes a result.
+int wbrt_tune_(wbrt_context *ctx, const char *key, int value)
+{
+	if (!ctx || !key) return fail(WBRT_ERR_INVALID, "null argument");
+	const std::string k(key);
+	if (k == "lpt") ctx->lpt = value != 0;
+	else if (k == "pilot_spp") ctx->pilot_spp = value > 0 ? value : 4;
+	else if (k == "box_tree_min") ctx->box_tree_min = value;
+	else if (k == "sphere_tree_min") ctx->sphere_tree_min = value;
+	else if (k == "bvh_min_idle") ctx->bvh_steal_min_idle = value;
+	else return fail(WBRT_ERR_INVALID, "unknown tuning key " + k);
+	ctx->recorded_spp = 0;
 	return WBRT_OK;
 }
 

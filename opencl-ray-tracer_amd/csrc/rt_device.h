@@ -109,6 +109,16 @@ bool wbrt_build_box_tree(const float4 *box_min, const float4 *box_max, const int
                          std::vector<float4> &nodes, std::vector<int> &box_of_rank, int &depth);
 void wbrt_append_sphere_tree(const float4 *sph_geom, const float *radius, int S, WbrtBvh &bvh);
 
+// Schedule arrays of one render launch (pilot costs, tile costs, launch order, histogram): buffers
+// the context allocated, or arrays a caller of the scheduler supplies.
+struct WbrtSchedule
+{
+	int *costs;        // pixels + pixels/64 + 1
+	int *tile_costs;   // pixels/64 + 1
+	int *order;        // pixels/64 + 1
+	unsigned *hist;    // 256
+};
+
 hipError_t wbrt_launch_render(const RenderParams &p, hipStream_t stream);
 hipError_t wbrt_launch_count(const RenderParams &p, hipStream_t stream);
 hipError_t wbrt_launch_ids(const RenderParams &p, hipStream_t stream);

@@ -601,7 +601,7 @@ def test_random_mesh_scenes(gpu_ctx, seed):
 
 
 @pytest.mark.parametrize("name", ["awkward", "stress36", "many_boxes"])
-def test_box_hierarchy_equals_box_loop(name, monkeypatch):
+def test_box_hierarchy_equals_box_loop(name):
     """The hierarchy over the bounding boxes (used from 48 boxes on, forced here from 2) queues exactly
     the boxes the reference's slab test accepts: same image as the loop over all boxes and as the oracle."""
     if name == "awkward":
@@ -612,9 +612,9 @@ def test_box_hierarchy_equals_box_loop(name, monkeypatch):
         scene, cam = _many_boxes_scene(), pkg.camera_main_cpp(160, 4, 50)
     images = {}
     for tree_min in (2, 1 << 30):
-        monkeypatch.setenv("WBRT_BOX_TREE_MIN", str(tree_min))
         ctx = pkg.Context(0)
         try:
+            ctx.tune("box_tree_min", tree_min)
             seeds = _setup(ctx, scene, cam, 4, 21)
             for mode in (pkg.MESH_BVH, pkg.MESH_BVH_STRICT):
                 ctx.set_mesh_mode(mode)
