@@ -110,6 +110,18 @@ int wbrt_render_frame(wbrt_context *ctx, const wbrt_camera *camera, int out_mode
 int wbrt_render_frame_device(wbrt_context *ctx, const wbrt_camera *camera, int out_mode,
                              void *device_image, void *stream);
 
+/* wbrt_render_frame_device for callers that cannot allocate (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same
+ * arguments, same result bit for bit; what differs: the launch schedule's arrays (pilot costs, tile
+ * costs, launch order, histogram) live in a file-scope device array of the library (8.4 MiB per GPU,
+ * held until the process ends) instead of buffers the context grows on demand; every launch runs its
+ * own pilot launch (no costs are carried over between launches) and is not seen by wbrt_set_timing.
+ * Calls no hipMalloc/hipFree or other allocating routine.  Limit: width*height <= 2097152 pixels
+ * (e.g. 1920x1080); larger frames return WBRT_ERR_INVALID.  Every such call on one GPU shares that
+ * GPU's array: calls that overlap in time on one GPU (different streams or contexts) race. */
+int wbrt_render_frame_device_noalloc(wbrt_context *ctx, const wbrt_camera *camera, int out_mode,
+                                     void *device_image, void *stream);
+
 /* Primary-hit primitive id per pixel for sample 0's first ray segment: sphere index,
  * sphere_count + triangle index, or -1 (miss).  No counterpart in the reference
  * (its HitRecord carries no id, gpu_kernel.cl:44-51); it exists for parity checking.

@@ -102,6 +102,7 @@ _SIGNATURES = {
     "wbrt_render_block": (C.c_int, [_P, C.POINTER(Camera), _P]),
     "wbrt_render_frame": (C.c_int, [_P, C.POINTER(Camera), C.c_int, _P]),
     "wbrt_render_frame_device": (C.c_int, [_P, C.POINTER(Camera), C.c_int, _P, _P]),
+    "wbrt_render_frame_device_noalloc": (C.c_int, [_P, C.POINTER(Camera), C.c_int, _P, _P]),
     "wbrt_primary_ids_frame": (C.c_int, [_P, C.POINTER(Camera), _P]),
     "wbrt_count_events_frame": (C.c_int, [_P, C.POINTER(Camera), _P]),
     "wbrt_tonemap_device": (C.c_int, [_P, _P, C.c_float, C.c_int32, C.c_int32, _P, _P]),
@@ -406,6 +407,11 @@ class Context:
     def render_frame_device(self, cam, device_ptr, out_mode=OUT_MEAN, stream=None):
         _check(lib().wbrt_render_frame_device(self._h, C.byref(cam), out_mode, C.c_void_p(device_ptr),
                                               C.c_void_p(stream) if stream else None))
+
+    def render_frame_device_noalloc(self, cam, device_ptr, out_mode=OUT_MEAN, stream=None):
+        """wbrt_render_frame_device without any allocation (schedule arrays in the library's static device array)."""
+        _check(lib().wbrt_render_frame_device_noalloc(self._h, C.byref(cam), out_mode, C.c_void_p(device_ptr),
+                                                      C.c_void_p(stream) if stream else None))
 
     def tune(self, key, value):
         """Private test/experiment hook (wbrt_tune_): thresholds that never change a result."""

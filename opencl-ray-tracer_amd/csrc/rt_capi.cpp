@@ -301,6 +301,13 @@ int wbrt_create(int device_ordinal, wbrt_context **out)
 	if (e != hipSuccess) { delete ctx; return fail(WBRT_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorName(e)); }
 	e = hipEventCreateWithFlags(&ctx->schedule_done, hipEventDisableTiming);
 	if (e != hipSuccess) { (void)hipStreamDestroy(ctx->stream); delete ctx; return fail(WBRT_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorName(e)); }
+	// this device's copy of the static schedule array (wbrt_render_frame_device_noalloc)
+	e = wbrt_scratch_init(device_ordinal);
+	if (e != hipSuccess)
+	{
+		(void)hipEventDestroy(ctx->schedule_done); (void)hipStreamDestroy(ctx->stream); delete ctx;
+		return fail(WBRT_ERR_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorName(e));
+	}
 	*out = ctx;
 	return WBRT_OK;
 }
@@ -541,6 +548,25 @@ int wbrt_render_frame_device(wbrt_context *ctx, const wbrt_camera *camera, int o
 	p.out = (float *)device_image;
 	p.out_mode = out_mode;
 	return timed_launch(ctx, p, (hipStream_t)stream);
+}
+
+int wbrt_render_frame_device_noalloc(wbrt_context *ctx, const wbrt_camera *camera, int out_mode, void *device_image, void *stream)
+{
+	int rc = bind(ctx);
+	if (rc) return rc;
+	if (!device_image) return fail(WBRT_ERR_INVALID, "null device image");
+	if (out_mode < 0 || out_mode > 2) return fail(WBRT_ERR_INVALID, "bad out_mode");
+	RenderParams p;
+	rc = make_params(ctx, camera, true, p);
+	if (rc) return rc;
+	if ((long long)p.width * p.height > (long long)WBRT_NOALLOC_MAX_PIXELS)
+		return fail(WBRT_ERR_INVALID, "wbrt_render_frame_device_noalloc serves frames of at most " + std::to_string(WBRT_NOALLOC_MAX_PIXELS) +
+		                                  " pixels (static schedule array); use wbrt_render_frame_device");
+	WbrtSchedule s;
+	if (!wbrt_scratch_schedule(ctx->device, s)) return fail(WBRT_ERR_HIP, "static schedule array not initialised for this device");
+	p.out = (float *)device_image;
+	p.out_mode = out_mode;
+	return scheduled_launch(ctx, p, (hipStream_t)stream, &s);
 }
 
 int wbrt_render_frame(wbrt_context *ctx, const wbrt_camera *camera, int out_mode, float *host_image)

@@ -109,8 +109,9 @@ bool wbrt_build_box_tree(const float4 *box_min, const float4 *box_max, const int
                          std::vector<float4> &nodes, std::vector<int> &box_of_rank, int &depth);
 void wbrt_append_sphere_tree(const float4 *sph_geom, const float *radius, int S, WbrtBvh &bvh);
 
-// Schedule arrays of one render launch (pilot costs, tile costs, launch order, histogram): buffers
-// the context allocated, or arrays a caller of the scheduler supplies.
+// Schedule arrays of one render launch (pilot costs, tile costs, launch order, histogram): either
+// buffers the context allocated, or slices of the library's static device array (the entry point
+// that allocates nothing).
 struct WbrtSchedule
 {
 	int *costs;        // pixels + pixels/64 + 1
@@ -118,6 +119,16 @@ struct WbrtSchedule
 	int *order;        // pixels/64 + 1
 	unsigned *hist;    // 256
 };
+// Largest launch (pixels of the frame) the static array serves, and its size in bytes.
+#define WBRT_NOALLOC_MAX_PIXELS (1 << 21)
+#define WBRT_ALIGN256(n) (((size_t)(n) + 255) & ~(size_t)255)
+#define WBRT_NOALLOC_COSTS_BYTES WBRT_ALIGN256(((size_t)WBRT_NOALLOC_MAX_PIXELS + WBRT_NOALLOC_MAX_PIXELS / 64 + 1) * sizeof(int))
+#define WBRT_NOALLOC_TILES_BYTES WBRT_ALIGN256(((size_t)WBRT_NOALLOC_MAX_PIXELS / 64 + 1) * sizeof(int))
+#define WBRT_NOALLOC_SCRATCH_BYTES (WBRT_NOALLOC_COSTS_BYTES + 2 * WBRT_NOALLOC_TILES_BYTES + 256 * sizeof(unsigned))
+// Looks up this device's copy of the static array (once per device, with that device current).
+hipError_t wbrt_scratch_init(int device);
+// The schedule arrays inside this device's copy; false before wbrt_scratch_init(device) succeeded.
+bool wbrt_scratch_schedule(int device, WbrtSchedule &s);
 
 hipError_t wbrt_launch_render(const RenderParams &p, hipStream_t stream);
 hipError_t wbrt_launch_count(const RenderParams &p, hipStream_t stream);

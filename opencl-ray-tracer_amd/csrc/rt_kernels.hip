@@ -22,6 +22,7 @@
 #include "rt_device.h"
 
 #include <math.h>
+#include <mutex>
 
 namespace {
 
@@ -1493,6 +1494,51 @@ inline unsigned grid_for(const RenderParams &p, int block)
 }
 
 } // namespace
+
+// Schedule arrays of the entry point that allocates nothing (wbrt_render_frame_device_noalloc): one
+// file-scope device array per GPU, held until the process ends.  Every launch on a GPU that goes
+// through that entry point shares it.  On the host the array's name only stands in for the symbol:
+// the device address is looked up once per device and used from then on.
+static __device__ __align__(256) unsigned char scratch[WBRT_NOALLOC_SCRATCH_BYTES];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+unsigned char *g_scratch_ptr[kMaxDevices] = {};
+} // namespace
+
+hipError_t wbrt_scratch_init(int device)
+{
+	if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+	std::lock_guard<std::mutex> lock(g_scratch_mutex);
+	if (g_scratch_ptr[device]) return hipSuccess;
+	int current = -1;
+	hipError_t e = hipGetDevice(&current);
+	if (e != hipSuccess) return e;
+	if (current != device) return hipErrorInvalidDevice; // the address belongs to the CURRENT device's copy
+	void *ptr = nullptr;
+	e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+	if (e != hipSuccess) return e;
+	if (!ptr) return hipErrorInvalidSymbol;
+	g_scratch_ptr[device] = (unsigned char *)ptr;
+	return hipSuccess;
+}
+
+bool wbrt_scratch_schedule(int device, WbrtSchedule &s)
+{
+	if (device < 0 || device >= kMaxDevices) return false;
+	unsigned char *base;
+	{
+		std::lock_guard<std::mutex> lock(g_scratch_mutex);
+		base = g_scratch_ptr[device];
+	}
+	if (!base) return false;
+	s.costs = (int *)base;
+	s.tile_costs = (int *)(base + WBRT_NOALLOC_COSTS_BYTES);
+	s.order = (int *)(base + WBRT_NOALLOC_COSTS_BYTES + WBRT_NOALLOC_TILES_BYTES);
+	s.hist = (unsigned *)(base + WBRT_NOALLOC_COSTS_BYTES + 2 * WBRT_NOALLOC_TILES_BYTES);
+	return true;
+}
 
 hipError_t wbrt_launch_render(const RenderParams &p, hipStream_t stream)
 {
