@@ -20,6 +20,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 
 namespace {
 
@@ -42,7 +43,27 @@ struct Prim
 	Bounds b;
 	double c[3]; // centroid of the bounds
 	double e;    // |e0||e1|
+	double m[3]; // (e0 x e1) / (|e0||e1|): |d . m| = |det| / (|e0||e1|) for a ray direction d; sign free (two-sided test)
+	double area; // |e0 x e1|
 	int index;   // position in the grouped triangle order
+};
+
+// Box around the m vectors of a set of triangles, each flipped into the set's own hemisphere.
+struct MBounds
+{
+	double lo[3], hi[3];
+	void reset() { for (int a = 0; a < 3; ++a) { lo[a] = DBL_MAX; hi[a] = -DBL_MAX; } }
+	void add(const double v[3]) { for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], v[a]); hi[a] = std::max(hi[a], v[a]); } }
+	void add(const MBounds &b) { for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], b.lo[a]); hi[a] = std::max(hi[a], b.hi[a]); } }
+	bool empty() const { return lo[0] > hi[0]; }
+	// lower bound of |d . m| over the box
+	double lower(const double d[3]) const
+	{
+		if (empty()) return 0.0;
+		double mn = 0.0, mx = 0.0;
+		for (int a = 0; a < 3; ++a) { mn += std::min(d[a] * lo[a], d[a] * hi[a]); mx += std::max(d[a] * lo[a], d[a] * hi[a]); }
+		return mn > 0.0 ? mn : mx < 0.0 ? -mx : 0.0;
+	}
 };
 
 float round_down(double v) { float f = (float)v; return (double)f > v ? std::nextafterf(f, -INFINITY) : f; }
@@ -181,6 +202,212 @@ struct Builder
 	}
 };
 
+// Builder of the hierarchies walked with PROVEN margins.  How far outside a node's box the reference's float
+// triangle test can still accept a hit depends on the ray: margin = R |d| min(0.35 E, 3.5e-6 / L) with E the largest
+// |e0||e1| below the node and L a lower bound of |d^ . m| over the node's m-box (see the kernel).  Boxes of triangles
+// that are large AND seen edge-on by some rays are therefore fat for those rays; a tree that only looks at positions
+// mixes such triangles with everything else near them.  This builder prices every candidate split with the boxes
+// widened by the margin averaged over 13 directions, and considers, besides the usual spatial planes, splits by
+// the components of m (orientation) and by log E (size), so that orientation classes and size classes separate
+// wherever that pays.
+struct MarginBuilder
+{
+	std::vector<Prim> prims;
+	WbrtBvh *out;
+	int depth_limit;
+	int max_depth = 0;
+	double rd; // nominal R |d| the margins are priced at
+
+	static constexpr int kLeaf = 4, kBins = 16, kKeys = 6, kDirs = 13;
+
+	static int balanced_levels(int count)
+	{
+		int leaves = (count + kLeaf - 1) / kLeaf, levels = 0;
+		while ((1 << levels) < leaves) ++levels;
+		return levels;
+	}
+
+	struct Agg
+	{
+		Bounds b; MBounds m; double e; int n;
+		void reset() { b.reset(); m.reset(); e = 0.0; n = 0; }
+		void add(const Prim &p) { b.add(p.b); m.add(p.m); e = std::max(e, p.e); ++n; }
+		void add(const Agg &a) { if (!a.n) return; b.add(a.b); m.add(a.m); e = std::max(e, a.e); n += a.n; }
+	};
+
+	double price(const Agg &a) const
+	{
+		if (!a.n) return 0.0;
+		static const double dirs[kDirs][3] = {
+			{ 1, 0, 0 }, { 0, 1, 0 }, { 0, 0, 1 },
+			{ 0.7071067811865476, 0.7071067811865476, 0 }, { 0.7071067811865476, -0.7071067811865476, 0 },
+			{ 0.7071067811865476, 0, 0.7071067811865476 }, { 0.7071067811865476, 0, -0.7071067811865476 },
+			{ 0, 0.7071067811865476, 0.7071067811865476 }, { 0, 0.7071067811865476, -0.7071067811865476 },
+			{ 0.5773502691896258, 0.5773502691896258, 0.5773502691896258 }, { 0.5773502691896258, 0.5773502691896258, -0.5773502691896258 },
+			{ 0.5773502691896258, -0.5773502691896258, 0.5773502691896258 }, { -0.5773502691896258, 0.5773502691896258, 0.5773502691896258 } };
+		double x = a.b.mx[0] - a.b.mn[0], y = a.b.mx[1] - a.b.mn[1], z = a.b.mx[2] - a.b.mn[2];
+		if (!(x >= 0 && y >= 0 && z >= 0) || !std::isfinite(x + y + z)) return DBL_MAX / 4;
+		const double by_e = std::isfinite(a.e) ? 0.35 * a.e : 1e30;
+		double sum = 0.0;
+		for (int k = 0; k < kDirs; ++k)
+		{
+			const double l = a.m.lower(dirs[k]);
+			double m = l > 2e-5 ? std::min(by_e, 3.5e-6 / l) : by_e;
+			m = std::min(m * rd, 4.0 * rd); // unbounded margins: priced as "always entered"
+			const double X = x + 2 * m, Y = y + 2 * m, Z = z + 2 * m;
+			sum += X * Y + Y * Z + Z * X;
+		}
+		return sum / kDirs * a.n;
+	}
+
+	// keys 0-2: centroid; 3-5: components of m; 6: size class, log2 E over the 16 octaves below the range's largest E
+	double key_of(const Prim &p, int key, double log_emax) const
+	{
+		if (key < 3) return p.c[key];
+		if (key < 6) return p.m[key - 3];
+		const double l = p.e > 0.0 ? (std::isfinite(p.e) ? std::log2(p.e) : 1100.0) : -1100.0;
+		return std::max(l, log_emax - 16.0);
+	}
+
+	int make_leaf(int first, int count)
+	{
+		const int base = (int)out->tri_index.size();
+		for (int i = 0; i < count; ++i) out->tri_index.push_back(prims[(size_t)first + i].index);
+		return ~((base << 4) | (count - 1));
+	}
+
+	// flips every m of the range into one hemisphere: that of the range's area-weighted mean
+	void orient(int first, int count)
+	{
+		int big = first;
+		for (int i = first; i < first + count; ++i) if (prims[(size_t)i].area > prims[(size_t)big].area) big = i;
+		const double *ref = prims[(size_t)big].m;
+		double mean[3] = { 0, 0, 0 };
+		for (int i = first; i < first + count; ++i)
+		{
+			Prim &p = prims[(size_t)i];
+			const double s = p.m[0] * ref[0] + p.m[1] * ref[1] + p.m[2] * ref[2] < 0 ? -1.0 : 1.0;
+			for (int a = 0; a < 3; ++a) mean[a] += s * p.m[a] * p.area;
+		}
+		for (int i = first; i < first + count; ++i)
+		{
+			Prim &p = prims[(size_t)i];
+			if (p.m[0] * mean[0] + p.m[1] * mean[1] + p.m[2] * mean[2] < 0) for (int a = 0; a < 3; ++a) p.m[a] = -p.m[a];
+		}
+	}
+
+	int build(int first, int count, int depth, Bounds &bounds, double &emax, MBounds &mb)
+	{
+		max_depth = std::max(max_depth, depth);
+		orient(first, count);
+		Agg all;
+		all.reset();
+		for (int i = first; i < first + count; ++i) all.add(prims[(size_t)i]);
+		bounds = all.b; emax = all.e; mb = all.m;
+		if (count <= kLeaf) return make_leaf(first, count);
+
+		double best = DBL_MAX;
+		int best_key = -1, best_bin = -1;
+		double best_lo = 0, best_scale = 0;
+		const double log_emax = all.e > 0.0 ? (std::isfinite(all.e) ? std::log2(all.e) : 1100.0) : -1100.0;
+		for (int key = 0; key < kKeys; ++key)
+		{
+			double lo = DBL_MAX, hi = -DBL_MAX;
+			for (int i = first; i < first + count; ++i) { const double k = key_of(prims[(size_t)i], key, log_emax); lo = std::min(lo, k); hi = std::max(hi, k); }
+			const double extent = hi - lo;
+			if (!(extent > 0.0) || !std::isfinite(extent)) continue;
+			const double scale = kBins / extent;
+			Agg bins[kBins], right[kBins];
+			for (int k = 0; k < kBins; ++k) bins[k].reset();
+			for (int i = first; i < first + count; ++i)
+			{
+				const Prim &p = prims[(size_t)i];
+				const int k = std::min(std::max((int)((key_of(p, key, log_emax) - lo) * scale), 0), kBins - 1);
+				bins[k].add(p);
+			}
+			Agg acc;
+			acc.reset();
+			for (int k = kBins - 1; k > 0; --k) { acc.add(bins[k]); right[k] = acc; }
+			acc.reset();
+			for (int k = 0; k < kBins - 1; ++k)
+			{
+				acc.add(bins[k]);
+				const int nl = acc.n, nr = count - nl;
+				if (!nl || !nr) continue;
+				// a lopsided split is taken only if the larger side can still be finished, balanced if need be,
+				// within the depth the kernel's stack allows
+				if (depth + 1 + balanced_levels(std::max(nl, nr)) > depth_limit) continue;
+				const double cost = price(acc) + price(right[k + 1]);
+				if (cost < best) { best = cost; best_key = key; best_bin = k; best_lo = lo; best_scale = scale; }
+			}
+		}
+		int mid = -1;
+		// Size classes first: while a minority of the range is much larger than the rest (E above a quarter of the
+		// largest), it gets a subtree of its own, so that its margins do not widen the boxes of the majority.  The
+		// one-level pricing below does not see that gain, which only shows further down.
+		if (getenv("WBRT_PEEL") ? atoi(getenv("WBRT_PEEL")) : 0)
+		if (count > 4 * kLeaf && all.e > 0.0 && std::isfinite(all.e))
+		{
+			const double cut = all.e / 4.0;
+			int big = 0;
+			for (int i = first; i < first + count; ++i) big += prims[(size_t)i].e > cut;
+			if (big > 0 && 2 * big <= count && depth + 1 + balanced_levels(count - big) <= depth_limit)
+			{
+				auto it = std::partition(prims.begin() + first, prims.begin() + first + count, [&](const Prim &p) { return !(p.e > cut); });
+				mid = (int)(it - prims.begin());
+				best_key = -1;
+			}
+		}
+		if (best_key >= 0)
+		{
+			auto it = std::partition(prims.begin() + first, prims.begin() + first + count, [&](const Prim &p) {
+				const int k = std::min(std::max((int)((key_of(p, best_key, log_emax) - best_lo) * best_scale), 0), kBins - 1);
+				return k <= best_bin;
+			});
+			mid = (int)(it - prims.begin());
+			if (mid == first || mid == first + count) mid = -1;
+		}
+		if (mid < 0)
+		{
+			int axis = 0;
+			Bounds cb;
+			cb.reset();
+			for (int i = first; i < first + count; ++i) cb.add(prims[(size_t)i].c);
+			for (int a = 1; a < 3; ++a) if (cb.mx[a] - cb.mn[a] > cb.mx[axis] - cb.mn[axis]) axis = a;
+			mid = first + count / 2;
+			std::nth_element(prims.begin() + first, prims.begin() + mid, prims.begin() + first + count,
+			                 [&](const Prim &a, const Prim &b) {
+				                 if (a.c[axis] != b.c[axis]) return a.c[axis] < b.c[axis];
+				                 return a.index < b.index;
+			                 });
+		}
+		const size_t node = out->nodes.size();
+		out->nodes.emplace_back();
+		out->mbox.resize(out->mbox.size() + 12);
+		Bounds lb, rb;
+		MBounds lm, rm;
+		double le, re;
+		const int left = build(first, mid - first, depth + 1, lb, le, lm);
+		const int right = build(mid, first + count - mid, depth + 1, rb, re, rm);
+		WbrtBvhNode n;
+		for (int a = 0; a < 3; ++a)
+		{
+			n.lmin[a] = round_down(lb.mn[a]); n.lmax[a] = round_up(lb.mx[a]);
+			n.rmin[a] = round_down(rb.mn[a]); n.rmax[a] = round_up(rb.mx[a]);
+		}
+		n.left = left; n.right = right;
+		n.le = round_up(le * 1.000001); n.re = round_up(re * 1.000001);
+		out->nodes[node] = n;
+		float *mbx = &out->mbox[12 * node];
+		for (int a = 0; a < 3; ++a)
+		{
+			mbx[a] = round_down(lm.lo[a]); mbx[3 + a] = round_up(lm.hi[a]);
+			mbx[6 + a] = round_down(rm.lo[a]); mbx[9 + a] = round_up(rm.hi[a]);
+		}
+		return (int)node;
+	}
+};
+
 } // namespace
 
 // tri_geom: the grouped triangle array of the device scene (3 float4 per triangle: p0.xyz e0.x |
@@ -191,6 +418,7 @@ void wbrt_build_bvh(const float4 *tri_geom, const int2 *ranges, int B, bool spli
 {
 	bvh.nodes.clear();
 	bvh.tri_index.clear();
+	bvh.mbox.clear();
 	bvh.roots.assign((size_t)B, WbrtBvhRoot{});
 	bvh.depth = 0;
 	for (int b = 0; b < B; ++b)
@@ -216,8 +444,34 @@ void wbrt_build_bvh(const float4 *tri_geom, const int2 *ranges, int B, bool spli
 				p.c[a] = 0.5 * p.b.mn[a] + 0.5 * p.b.mx[a];
 			}
 			p.e = std::sqrt(e0[0] * e0[0] + e0[1] * e0[1] + e0[2] * e0[2]) * std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+			const double nx = e0[1] * e1[2] - e0[2] * e1[1], ny = e0[2] * e1[0] - e0[0] * e1[2], nz = e0[0] * e1[1] - e0[1] * e1[0];
+			p.area = std::sqrt(nx * nx + ny * ny + nz * nz);
+			if (p.e > 0.0 && std::isfinite(p.e) && std::isfinite(p.area)) { p.m[0] = nx / p.e; p.m[1] = ny / p.e; p.m[2] = nz / p.e; }
+			else { p.m[0] = p.m[1] = p.m[2] = 0.0; p.area = 0.0; } // the origin in an m-box: no bound from it
 			if (!std::isfinite(p.e)) p.e = DBL_MAX;
 			p.index = first + i;
+		}
+		if (split_by_e)
+		{
+			MarginBuilder mbld;
+			mbld.prims = std::move(prims);
+			mbld.out = &bvh;
+			mbld.depth_limit = WBRT_BVH_STACK;
+			Bounds all;
+			all.reset();
+			for (const Prim &p : mbld.prims) for (int a = 0; a < 3; ++a) if (p.b.mn[a] > -DBL_MAX / 2 && p.b.mx[a] < DBL_MAX / 2) { all.mn[a] = std::min(all.mn[a], p.b.mn[a]); all.mx[a] = std::max(all.mx[a], p.b.mx[a]); }
+			double diag = 0.0;
+			for (int a = 0; a < 3; ++a) if (all.mx[a] > all.mn[a]) diag += (all.mx[a] - all.mn[a]) * (all.mx[a] - all.mn[a]);
+			mbld.rd = 4.0 * std::sqrt(diag) + 1e-30;
+			Bounds rb;
+			MBounds rm;
+			double re;
+			root.ref = mbld.build(0, count, 0, rb, re, rm);
+			for (int a = 0; a < 3; ++a) { root.mn[a] = round_down(rb.mn[a]); root.mx[a] = round_up(rb.mx[a]); }
+			root.e = round_up(re * 1.000001);
+			root.empty = 0;
+			bvh.depth = std::max(bvh.depth, mbld.max_depth);
+			continue;
 		}
 		Builder bl;
 		bl.prims = std::move(prims);
@@ -231,6 +485,12 @@ void wbrt_build_bvh(const float4 *tri_geom, const int2 *ranges, int B, bool spli
 		root.e = round_up(re * 1.000001);
 		root.empty = 0;
 		bvh.depth = std::max(bvh.depth, bl.max_depth);
+	}
+	if (bvh.mbox.size() != bvh.nodes.size() * 12) // trees built without m-boxes: nothing is known
+	{
+		bvh.mbox.assign(bvh.nodes.size() * 12, 0.0f);
+		for (size_t n = 0; n < bvh.nodes.size(); ++n)
+			for (int k = 0; k < 12; ++k) bvh.mbox[12 * n + k] = (k % 6) < 3 ? -1.0f : 1.0f;
 	}
 }
 
@@ -271,6 +531,8 @@ void wbrt_append_sphere_tree(const float4 *sph_geom, const float *radius, int S,
 	root.empty = 0;
 	bvh.roots.push_back(root);
 	bvh.depth = std::max(bvh.depth, bl.max_depth);
+	while (bvh.mbox.size() < bvh.nodes.size() * 12)
+		for (int k = 0; k < 12; ++k) bvh.mbox.push_back((k % 6) < 3 ? -1.0f : 1.0f);
 }
 
 // Test hook (not in the public header): runs the builder on host arrays and copies the result

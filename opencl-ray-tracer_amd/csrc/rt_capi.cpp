@@ -79,11 +79,13 @@ struct wbrt_context
 	DevBuf top_nodes, top_box;    // hierarchy over the boxes (scenes with box_tree_min or more boxes)
 	int top_depth = 0;            // 0: no such hierarchy
 	int box_tree_min = 48;        // measured crossover between 36 and 64 boxes
-	DevBuf bvh_nodes[2], bvh_tris[2], bvh_roots[2]; // [0] plain surface-area trees, [1] built for the strict margins
+	DevBuf bvh_nodes[2], bvh_tris[2], bvh_roots[2]; // [0] plain surface-area trees (capped margins), [1] built for the proven margins
+	DevBuf bvh_mbox;              // m-boxes of the nodes of variant [1]
 	const float4 *bvh_ptr[2][3] = {};
 	int bvh_depth[2] = {0, 0};
 	int mesh_mode = WBRT_MESH_BVH;
 	int bvh_steal_min_idle = 8;
+	int strict_loop_max = 4096;   // proven-margin mode: meshes up to this many triangles use the cooperative loop
 	float bvh_rho = 2e-4f; // WBRT_MESH_BVH: box margin as a fraction of the ray's distance bound
 	DevBuf sky, seeds, image, ids, counters, rgb8, costs, tile_costs, order, hist;
 	int lpt = 1;        // longest-first scheduling from a pilot pass
@@ -154,13 +156,14 @@ int make_params(wbrt_context *ctx, const wbrt_camera *cam, bool whole_frame, Ren
 	p.seeds = (const uint32_t *)ctx->seeds.p;
 	p.sc = ctx->sc;
 	// strict margins on a small mesh widen every box to the whole mesh: the cooperative loop is faster there
-	const bool strict_small = ctx->mesh_mode == WBRT_MESH_BVH_STRICT && ctx->sc.T <= 4096 && !ctx->have_sphere_tree;
+	const bool strict_small = ctx->mesh_mode == WBRT_MESH_BVH_STRICT && ctx->sc.T <= ctx->strict_loop_max && !ctx->have_sphere_tree;
 	if (ctx->mesh_mode != WBRT_MESH_LOOP && ctx->have_bvh && !strict_small)
 	{
 		const int variant = ctx->mesh_mode == WBRT_MESH_BVH_STRICT ? 1 : 0;
 		p.sc.bvh_nodes = ctx->bvh_ptr[variant][0];
 		p.sc.bvh_tris = ctx->bvh_ptr[variant][1];
 		p.sc.bvh_roots = ctx->bvh_ptr[variant][2];
+		p.sc.bvh_mbox = variant == 1 ? (const uint4 *)ctx->bvh_mbox.p : nullptr;
 		p.sc.bvh_box_slots = WBRT_BVH_STACK - ctx->bvh_depth[variant] + 1;
 		if (ctx->top_depth > 0)
 		{
@@ -322,7 +325,7 @@ int wbrt_destroy(wbrt_context *ctx)
 	DevBuf *all[] = { &ctx->sph_geom, &ctx->sph_radius, &ctx->sph_mat_a, &ctx->sph_mat_b, &ctx->tri_geom,
 	                  &ctx->tri_mat_a, &ctx->tri_mat_b, &ctx->tri_orig, &ctx->box_min, &ctx->box_max,
 	                  &ctx->box_range, &ctx->bvh_nodes[0], &ctx->bvh_tris[0], &ctx->bvh_roots[0],
-	                  &ctx->bvh_nodes[1], &ctx->bvh_tris[1], &ctx->bvh_roots[1], &ctx->top_nodes, &ctx->top_box, &ctx->sky, &ctx->seeds, &ctx->image, &ctx->ids, &ctx->counters, &ctx->rgb8,
+	                  &ctx->bvh_nodes[1], &ctx->bvh_tris[1], &ctx->bvh_roots[1], &ctx->bvh_mbox, &ctx->top_nodes, &ctx->top_box, &ctx->sky, &ctx->seeds, &ctx->image, &ctx->ids, &ctx->counters, &ctx->rgb8,
 	                  &ctx->costs, &ctx->tile_costs, &ctx->order, &ctx->hist };
 	for (DevBuf *b : all) b->release();
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -461,6 +464,32 @@ int wbrt_upload_scene(wbrt_context *ctx, const wbrt_sphere *spheres, int32_t S,
 			broots[2 * b + 1] = make_float4(r.mx[0], r.mx[1], r.mx[2], r.empty ? -1.0f : r.e);
 		}
 		UP(bvh_nodes[variant], bnodes); UP(bvh_tris[variant], btris); UP(bvh_roots[variant], broots);
+		if (variant == 1)
+		{
+			// m-box components as bytes, rounded outwards: lower bounds down, upper bounds up (b -> b/127 - 1)
+			auto pack = [](const float *v, bool up) {
+				unsigned w = 0;
+				for (int a = 0; a < 3; ++a)
+				{
+					const double x = ((double)v[a] + 1.0) * 127.0;
+					double b = up ? std::ceil(x) : std::floor(x);
+					if (up && b / 127.0 - 1.0 < (double)v[a]) b += 1.0;
+					if (!up && b / 127.0 - 1.0 > (double)v[a]) b -= 1.0;
+					if (!(b >= 0.0)) b = 0.0;        // also NaN: the widest box
+					if (!(b <= 254.0)) b = 254.0;
+					if (!(v[a] == v[a])) b = up ? 254.0 : 0.0;
+					w |= (unsigned)b << (8 * a);
+				}
+				return w;
+			};
+			std::vector<uint4> mb(bvh.nodes.size());
+			for (size_t n = 0; n < bvh.nodes.size(); ++n)
+			{
+				const float *m = &bvh.mbox[12 * n];
+				mb[n] = make_uint4(pack(m, false), pack(m + 3, true), pack(m + 6, false), pack(m + 9, true));
+			}
+			UP(bvh_mbox, mb);
+		}
 		ctx->bvh_ptr[variant][0] = (const float4 *)ctx->bvh_nodes[variant].p;
 		ctx->bvh_ptr[variant][1] = (const float4 *)ctx->bvh_tris[variant].p;
 		ctx->bvh_ptr[variant][2] = (const float4 *)ctx->bvh_roots[variant].p;
@@ -471,6 +500,7 @@ int wbrt_upload_scene(wbrt_context *ctx, const wbrt_sphere *spheres, int32_t S,
 #undef UP
 	SceneDev &sc = ctx->sc;
 	sc.bvh_nodes = sc.bvh_tris = sc.bvh_roots = nullptr; // chosen per render (make_params)
+	sc.bvh_mbox = nullptr;
 	sc.bvh_rho = 0.0f;
 	sc.sph_tree = 0;
 	sc.sph_geom = (const float4 *)ctx->sph_geom.p; sc.sph_radius = (const float *)ctx->sph_radius.p;
@@ -711,6 +741,7 @@ int wbrt_tune_(wbrt_context *ctx, const char *key, int value)
 	else if (k == "box_tree_min") ctx->box_tree_min = value;
 	else if (k == "sphere_tree_min") ctx->sphere_tree_min = value;
 	else if (k == "bvh_min_idle") ctx->bvh_steal_min_idle = value;
+	else if (k == "strict_loop_max") ctx->strict_loop_max = value;
 	else return fail(WBRT_ERR_INVALID, "unknown tuning key " + k);
 	ctx->recorded_spp = 0;
 	return WBRT_OK;

@@ -46,6 +46,8 @@ struct SceneDev
 	const float4 *bvh_nodes;  // 4 per node: lmin.xyz lmax.x | lmax.yz rmin.xy | rmin.z rmax.xyz | left right E_left E_right
 	const float4 *bvh_tris;   // 3 per leaf slot: tri_geom layout, fourth word of the last float4 = position in the grouped order
 	const float4 *bvh_roots;  // 2 per box: min.xyz ref | max.xyz E   (E < 0: box without triangles)
+	const uint4  *bvh_mbox;   // 1 per node (proven-margin trees only): bytes 0-2 of x|y|z|w = left lo, left hi, right lo, right hi of the
+	                          // children's m-boxes, m = (e0 x e1)/(|e0||e1|), byte b -> b/127 - 1
 	float bvh_rho;
 	int sph_tree;             // 1: bvh_roots[B] is a hierarchy over the spheres (leaf slot: center.xyz r^2 | - | - index - -)
 	int bvh_box_slots;        // stack entries free for queued boxes: WBRT_BVH_STACK - tree depth + 1
@@ -102,6 +104,9 @@ struct WbrtBvh
 	std::vector<WbrtBvhNode> nodes;
 	std::vector<int> tri_index; // leaf slot -> position in the grouped triangle order
 	std::vector<WbrtBvhRoot> roots;
+	// 12 per node (left lo.xyz hi.xyz, right lo.xyz hi.xyz): box around (e0 x e1)/(|e0||e1|) of the triangles below each
+	// child, each vector flipped into the child's own hemisphere; [-1,1]^3 where nothing is known
+	std::vector<float> mbox;
 	int depth = 0;
 };
 void wbrt_build_bvh(const float4 *tri_geom, const int2 *ranges, int B, bool split_by_e, WbrtBvh &bvh);
