@@ -247,12 +247,12 @@ struct MarginBuilder
 			{ 0.5773502691896258, -0.5773502691896258, 0.5773502691896258 }, { -0.5773502691896258, 0.5773502691896258, 0.5773502691896258 } };
 		double x = a.b.mx[0] - a.b.mn[0], y = a.b.mx[1] - a.b.mn[1], z = a.b.mx[2] - a.b.mn[2];
 		if (!(x >= 0 && y >= 0 && z >= 0) || !std::isfinite(x + y + z)) return DBL_MAX / 4;
-		const double by_e = std::isfinite(a.e) ? 0.35 * a.e : 1e30;
+		const double by_e = std::isfinite(a.e) ? 0.20 * a.e : 1e30;
 		double sum = 0.0;
 		for (int k = 0; k < kDirs; ++k)
 		{
 			const double l = a.m.lower(dirs[k]);
-			double m = l > 2e-5 ? std::min(by_e, 3.5e-6 / l) : by_e;
+			double m = l > 2e-5 ? std::min(by_e, 2.05e-6 / l) : by_e;
 			m = std::min(m * rd, 4.0 * rd); // unbounded margins: priced as "always entered"
 			const double X = x + 2 * m, Y = y + 2 * m, Z = z + 2 * m;
 			sum += X * Y + Y * Z + Z * X;

@@ -656,15 +656,12 @@ __device__ __forceinline__ void bvh_load_ray(const StealLds &w, int slot, BvhRay
 }
 
 // Lower bound of |d . m| over a node's m-box (m = (e0 x e1)/(|e0||e1|) of the triangles below it, bytes b -> b/127 - 1,
-// rounded outwards by the builder): |det| of the reference's test is at least that times |e0||e1|.
-__device__ __forceinline__ float mbox_lower(unsigned lo3, unsigned hi3, F3 d)
+// rounded outwards by the builder): |det| of the reference's test is at least that times |e0||e1|.  dk = d / 127.
+__device__ __forceinline__ float mbox_lower(unsigned lo3, unsigned hi3, F3 d, F3 dk)
 {
-	const float k = 1.0f / 127.0f;
-	const float lx = __builtin_fmaf((float)(lo3 & 255u), k, -1.0f), ly = __builtin_fmaf((float)((lo3 >> 8) & 255u), k, -1.0f),
-	            lz = __builtin_fmaf((float)((lo3 >> 16) & 255u), k, -1.0f);
-	const float hx = __builtin_fmaf((float)(hi3 & 255u), k, -1.0f), hy = __builtin_fmaf((float)((hi3 >> 8) & 255u), k, -1.0f),
-	            hz = __builtin_fmaf((float)((hi3 >> 16) & 255u), k, -1.0f);
-	const float ax = d.x * lx, bx = d.x * hx, ay = d.y * ly, by = d.y * hy, az = d.z * lz, bz = d.z * hz;
+	const float ax = __builtin_fmaf((float)(lo3 & 255u), dk.x, -d.x), bx = __builtin_fmaf((float)(hi3 & 255u), dk.x, -d.x);
+	const float ay = __builtin_fmaf((float)((lo3 >> 8) & 255u), dk.y, -d.y), by = __builtin_fmaf((float)((hi3 >> 8) & 255u), dk.y, -d.y);
+	const float az = __builtin_fmaf((float)((lo3 >> 16) & 255u), dk.z, -d.z), bz = __builtin_fmaf((float)((hi3 >> 16) & 255u), dk.z, -d.z);
 	const float mn = fminf(ax, bx) + fminf(ay, by) + fminf(az, bz);
 	const float mx = fmaxf(ax, bx) + fmaxf(ay, by) + fmaxf(az, bz);
 	return fmaxf(fmaxf(mn, -mx), 0.0f);
@@ -672,20 +669,23 @@ __device__ __forceinline__ float mbox_lower(unsigned lo3, unsigned hi3, F3 d)
 
 // Proven box margin of one child for one ray (triangle hierarchies, WBRT_MESH_BVH).  With u = 2^-24, s = o - p0,
 // K = |d||e0||e1| and det the FLOAT determinant of gpu_kernel.cl:494, forward error analysis of gpu_kernel.cl:489-520
-// bounds the distance between the ray point o + t0 d of an ACCEPTED hit and the triangle by 26.5 u |s| K / |det| (+ a few
-// u (|s| + |e0| + |e1|), covered by the slop).  Two bounds of K / |det| hold for every triangle below the child:
+// (every rounding of the cross products, dot products, the reciprocal and the three final products, Cramer's identity
+// s det = Nu e0 + Nv e1 - Nt d for the exact numerators) bounds the distance between the ray point o + t0 d of an
+// ACCEPTED hit and the triangle by 26.5 u |s| K / |det|, plus a few u (|s| + |e0| + |e1|) that the slop covers.
+// Two bounds of K / |det| hold for every triangle below the child:
 //   |det| >= 1e-5 (the test's own cutoff)                        ->  K/|det| <= 1e5 |d| E,  E = max |e0||e1|;
-//   |det| >= |e0||e1| (L - 6u|d|),  L = mbox_lower(child, d)     ->  K/|det| <= 1.001 |d| / L  once L > 2e-5 |d|.
-// |s| <= distance from o to the far corner of the child's box.  The margin is the smaller bound times 2.2 (safety).
-__device__ __forceinline__ float strict_pad(float ox, float oy, float oz, F3 d, float dlen, float e_limit, float slop0,
+//   |det| >= |e0||e1| (L - 6u|d|),  L = mbox_lower(child, d)     ->  K/|det| <= 1.02 |d| / L  once L > 2e-5 |d|.
+// |s| <= distance from o to the far corner of the child's box.  Constants: 26.5 u x 1.25 = 2.0e-6 (the factor covers
+// the second-order terms and the roundings of this function itself).
+__device__ __forceinline__ float strict_pad(float ox, float oy, float oz, F3 d, F3 dk, float dlen, float e_limit, float slop0,
                                             float mnx, float mny, float mnz, float mxx, float mxy, float mxz, float E, unsigned lo3, unsigned hi3)
 {
 	const float fx = fmaxf(fabsf(mnx - ox), fabsf(mxx - ox)), fy = fmaxf(fabsf(mny - oy), fabsf(mxy - oy)), fz = fmaxf(fabsf(mnz - oz), fabsf(mxz - oz));
-	const float far = __builtin_amdgcn_sqrtf(fx * fx + fy * fy + fz * fz) * 1.00001f;
-	const float L = mbox_lower(lo3, hi3, d) - 2e-6f * dlen;
-	const float by_e = E <= e_limit ? 0.35f * E : INFINITY;
-	const float by_det = L > 2e-5f * dlen ? 3.5e-6f * __builtin_amdgcn_rcpf(L) * 1.00001f : INFINITY;
-	return fminf(by_e, by_det) * (far * dlen) + (3e-6f * far + slop0);
+	const float far = __builtin_amdgcn_sqrtf(__builtin_fmaf(fx, fx, __builtin_fmaf(fy, fy, fz * fz))) * 1.00001f;
+	const float L = mbox_lower(lo3, hi3, d, dk) - 2e-6f * dlen;
+	const float by_e = E <= e_limit ? 0.20f * E : INFINITY;
+	const float by_det = L > 2e-5f * dlen ? 2.05e-6f * __builtin_amdgcn_rcpf(L) : INFINITY;
+	return __builtin_fmaf(fminf(by_e, by_det), far * dlen, __builtin_fmaf(3e-6f, far, slop0));
 }
 
 // margins of ray r against the hierarchy of `box`; returns its root reference (INT_MIN: no triangles)
@@ -902,8 +902,9 @@ __device__ __forceinline__ void triangles_steal(const SceneDev &sc, int (*stack)
 					else
 					{
 						const uint4 mq = sc.bvh_mbox[node];
-						pad_l = strict_pad(r.o.x, r.o.y, r.o.z, r.d, r.dlen, r.e_limit, r.slop, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q3.z, mq.x, mq.y);
-						pad_r = strict_pad(r.o.x, r.o.y, r.o.z, r.d, r.dlen, r.e_limit, r.slop, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.w, mq.z, mq.w);
+						const F3 dk = r.d * (1.0f / 127.0f);
+						pad_l = strict_pad(r.o.x, r.o.y, r.o.z, r.d, dk, r.dlen, r.e_limit, r.slop, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q3.z, mq.x, mq.y);
+						pad_r = strict_pad(r.o.x, r.o.y, r.o.z, r.d, dk, r.dlen, r.e_limit, r.slop, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.w, mq.z, mq.w);
 					}
 					vl = bvh_box(f3(r.o.x + pad_l, r.o.y + pad_l, r.o.z + pad_l), f3(r.o.x - pad_l, r.o.y - pad_l, r.o.z - pad_l), r.inv,
 					             q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, best, lo_l);
@@ -1096,7 +1097,7 @@ __device__ __forceinline__ void init_lane(const RenderParams &p, Lane &L, int gi
 // BOXTREE: the scene comes with a hierarchy over its boxes (sc.top_nodes); a build of its own, so that scenes
 // with few boxes keep the registers of the plain loop over the boxes.
 template <bool STATS, bool MESH, bool BOXTREE = false>
-__global__ __launch_bounds__(WBRT_RENDER_BLOCK) void k_render(const RenderParams p)
+__global__ __launch_bounds__(WBRT_RENDER_BLOCK, (MESH && !STATS) ? 4 : 1) void k_render(const RenderParams p)
 {
 	__shared__ TriTiles s_tiles[MESH && STATS ? WBRT_RENDER_BLOCK / 64 : 1]; // counting build: sequential staged loop, one per wave
 	__shared__ unsigned long long s_best[MESH && !STATS ? WBRT_RENDER_BLOCK / 64 : 1][64];

@@ -127,6 +127,53 @@ static void build_mboxes(int variant)
 	}
 }
 
+// Per child: ratio[a] = max over triangles of E_tri sqrt(1 - n_a^2) / E_child (in-plane share of the margin along axis a),
+// and the largest sliver factor sigma = |e0||e1| / |e0 x e1| (the out-of-plane part of the margin is 2.2e-6 sigma S).
+struct Aniso { float ratio[3], sigma; };
+static std::vector<Aniso> g_aniso; // variant 1 only, 2 per node
+static Aniso aniso_of(const std::vector<int> &tris)
+{
+	Aniso a = { { 0, 0, 0 }, 0 };
+	float emax = 0;
+	std::vector<float> ea[3];
+	for (int t : tris)
+	{
+		const float4 g0 = g_geom[3 * (size_t)t], g1 = g_geom[3 * (size_t)t + 1], g2 = g_geom[3 * (size_t)t + 2];
+		V3 e0 = { g0.w, g1.x, g1.y }, e1 = { g1.z, g1.w, g2.x };
+		V3 n = cross(e0, e1);
+		float E = len(e0) * len(e1), A = len(n);
+		emax = std::fmax(emax, E);
+		float sig = A > 0 ? E / A : INFINITY;
+		a.sigma = std::fmax(a.sigma, sig);
+		const float nn[3] = { A > 0 ? n.x / A : 0, A > 0 ? n.y / A : 0, A > 0 ? n.z / A : 0 };
+		for (int k = 0; k < 3; ++k) a.ratio[k] = std::fmax(a.ratio[k], E * std::sqrt(std::fmax(0.0f, 1 - nn[k] * nn[k])));
+	}
+	for (int k = 0; k < 3; ++k) a.ratio[k] = emax > 0 ? std::fmin(1.0f, a.ratio[k] / emax * 1.0001f) : 1.0f;
+	return a;
+}
+static void build_aniso()
+{
+	const WbrtBvh &bvh = g_bvh[1];
+	g_aniso.resize(bvh.nodes.size() * 2);
+	for (size_t n = 0; n < bvh.nodes.size(); ++n)
+	{
+		std::vector<int> l, r;
+		collect(bvh, bvh.nodes[n].left, l);
+		collect(bvh, bvh.nodes[n].right, r);
+		g_aniso[2 * n] = aniso_of(l);
+		g_aniso[2 * n + 1] = aniso_of(r);
+	}
+}
+static bool box_hit3(V3 o, V3 inv, const float *mn, const float *mx, const float *pad, float best, float &lo)
+{
+	float tx1 = (mn[0] - pad[0] - o.x) * inv.x, tx2 = (mx[0] + pad[0] - o.x) * inv.x;
+	float ty1 = (mn[1] - pad[1] - o.y) * inv.y, ty2 = (mx[1] + pad[1] - o.y) * inv.y;
+	float tz1 = (mn[2] - pad[2] - o.z) * inv.z, tz2 = (mx[2] + pad[2] - o.z) * inv.z;
+	lo = std::fmax(std::fmax(std::fmin(tx1, tx2), std::fmin(ty1, ty2)), std::fmin(tz1, tz2));
+	float hi = std::fmin(std::fmin(std::fmax(tx1, tx2), std::fmax(ty1, ty2)), std::fmax(tz1, tz2));
+	return !(lo > hi) && !(hi < 0.0f) && !(lo > best);
+}
+
 static float mbox_lb(const MBox &b, V3 d)
 {
 	const float dd[3] = { d.x, d.y, d.z };
@@ -180,7 +227,7 @@ static int walk(const WbrtBvh &bvh, int variant, const Ray &r, int mode, float r
 				const float rl = rnode(n.lmin, n.lmax), rr = rnode(n.rmin, n.rmax);
 				pl = n.le <= e_limit ? 0.35f * n.le * rl * dlen + slop : INFINITY;
 				pr = n.re <= e_limit ? 0.35f * n.re * rr * dlen + slop : INFINITY;
-				if (mode == 4)
+				if (mode == 4 || mode == 5)
 				{
 					// the builder's own m-boxes; R = distance to the far corner of the child's box only
 					const float fl_ = far2(r.o, n.lmin, n.lmax), fr_ = far2(r.o, n.rmin, n.rmax);
@@ -205,6 +252,22 @@ static int walk(const WbrtBvh &bvh, int variant, const Ray &r, int mode, float r
 			float lo_l, lo_r;
 			bool vl = box_hit(r.o, inv, n.lmin, n.lmax, pl, best, lo_l);
 			bool vr = box_hit(r.o, inv, n.rmin, n.rmax, pr, best, lo_r);
+			if (mode == 5)
+			{
+				// anisotropic: in-plane share per axis + out-of-plane part
+				const float fl_ = far2(r.o, n.lmin, n.lmax), fr_ = far2(r.o, n.rmin, n.rmax);
+				const float o1 = std::fabs(r.o.x) + std::fabs(r.o.y) + std::fabs(r.o.z);
+				const Aniso &al = g_aniso[2 * (size_t)node], &ar = g_aniso[2 * (size_t)node + 1];
+				float p3l[3], p3r[3];
+				for (int a = 0; a < 3; ++a)
+				{
+					const float sl = 3e-6f * (fl_ + o1), sr = 3e-6f * (fr_ + o1);
+					p3l[a] = std::fmin(pl, (pl - sl) * al.ratio[a] + 2.2e-6f * al.sigma * fl_ + sl);
+					p3r[a] = std::fmin(pr, (pr - sr) * ar.ratio[a] + 2.2e-6f * ar.sigma * fr_ + sr);
+				}
+				vl = box_hit3(r.o, inv, n.lmin, n.lmax, p3l, best, lo_l);
+				vr = box_hit3(r.o, inv, n.rmin, n.rmax, p3r, best, lo_r);
+			}
 			if (mode == 4)
 			{
 				float dummy;
@@ -286,6 +349,7 @@ int main(int argc, char **argv)
 		wbrt_build_bvh(g_geom.data(), &range, 1, variant == 1, g_bvh[variant]);
 		std::printf("variant %d: %zu nodes, depth %d\n", variant, g_bvh[variant].nodes.size(), g_bvh[variant].depth);
 		build_mboxes(variant);
+		if (variant == 1) build_aniso();
 		if (variant == 1 && std::getenv("DUMP")) dump(g_bvh[1], g_bvh[1].roots[0].ref, 0, std::atoi(std::getenv("DUMP")));
 	}
 	wbrt_camera cam;
@@ -335,7 +399,7 @@ int main(int argc, char **argv)
 	struct Cfg { const char *name; int variant, mode; float rho; };
 	const Cfg cfgs[] = { { "capped 2e-4 (plain tree)", 0, 0, 2e-4f }, { "strict shipped (split tree)", 1, 1, 0 }, { "strict shipped (plain tree)", 0, 1, 0 },
 	                     { "strict per-node R (split tree)", 1, 2, 0 }, { "strict per-node R (plain tree)", 0, 2, 0 },
-	                     { "strict + M boxes (split tree)", 1, 3, 0 }, { "strict, builder m-boxes (margin tree)", 1, 4, 0 }, { "strict + M boxes (plain tree)", 0, 3, 0 } };
+	                     { "strict + M boxes (split tree)", 1, 3, 0 }, { "strict, builder m-boxes (margin tree)", 1, 4, 0 }, { "  + anisotropic margins", 1, 5, 0 }, { "strict + M boxes (plain tree)", 0, 3, 0 } };
 	for (const Cfg &c : cfgs)
 	{
 		Stats cs, bs;
