@@ -220,11 +220,11 @@ def main():
         pilot_ms = (time.perf_counter() - t1) / 5 * 1e3
         ctx.set_schedule_reuse(True)
 
-    # mesh configuration: the same step in the mesh mode whose result is proven equal to the reference's
-    # triangle loop (the default mode's is equal in every comparison made so far, see include/ocl_rt_amd.h)
-    strict_ms = None
+    # mesh configuration: the same step in the opt-in capped-margin walk (not proven equal to the reference's
+    # triangle loop; the timed steps above ran the default, proven mode), for comparison
+    capped_ms = None
     if args.config == "mesh" and nfl == 1:
-        ctx.set_mesh_mode(pkg.MESH_BVH_STRICT)
+        ctx.set_mesh_mode(pkg.MESH_BVH_CAPPED)
         step()
         step()
         barrier()
@@ -232,7 +232,7 @@ def main():
         for _ in range(3):
             step()
         barrier()
-        strict_ms = (time.perf_counter() - t1) / 3 * 1e3
+        capped_ms = (time.perf_counter() - t1) / 3 * 1e3
         ctx.set_mesh_mode(pkg.MESH_BVH)
 
     if args.config == "uhd":
@@ -286,9 +286,9 @@ def main():
                         "counted FLOPs issue as separate mul/add (measured ceiling 0.87 G wave-inst/s/SIMD = 57 TFLOP/s)",
             },
         }
-        if strict_ms is not None:
-            result["config"]["mesh_mode"] = "WBRT_MESH_BVH (default)"
-            result["config"]["ms_per_step_in_WBRT_MESH_BVH_STRICT"] = round(strict_ms, 3)
+        if capped_ms is not None:
+            result["config"]["mesh_mode"] = "WBRT_MESH_BVH (default: hierarchy walk with proven margins, same result as the reference's triangle loop)"
+            result["config"]["ms_per_step_in_WBRT_MESH_BVH_CAPPED"] = round(capped_ms, 3)
         if args.config in ("mesh", "stress"):
             result["config"].pop("readme_published_gpu_frame_s", None)
             # the FLOP count prices every triangle test the reference's loop performs; the hierarchy walk

@@ -144,23 +144,26 @@ int wbrt_synchronize(wbrt_context *ctx);
 /* How the render kernel finds the nearest triangle of a bounding box whose slab test
  * passed (gpu_kernel.cl:374-391).  No counterpart in the reference, which always loops.
  *   WBRT_MESH_LOOP        every triangle of the box is tested, as the reference does;
- *   WBRT_MESH_BVH_STRICT  a hierarchy of boxes built on upload is walked; a subtree is
- *                         skipped only if a forward error bound of the reference's float
- *                         triangle test (at its own |det| >= 1e-5 cutoff) proves that none
- *                         of its triangles can be accepted: same result as the loop;
- *   WBRT_MESH_BVH         (default) as above with the box margin capped at 2e-4 of the
- *                         ray's distance to the mesh.  Differs from the loop only for a ray
- *                         within about half a degree of a triangle's plane that passes that
- *                         triangle at more than the margin: there the reference's own
- *                         accept/reject decision is rounding noise.
+ *   WBRT_MESH_BVH         (default) a hierarchy of boxes built on upload is walked; a subtree is
+ *                         skipped only if a forward error bound of the reference's float triangle
+ *                         test proves that the test accepts none of its triangles for this ray
+ *                         (margin per ray and node from the distance to the node, the largest
+ *                         |e0||e1| below it with the test's own |det| >= 1e-5 cutoff, and a lower
+ *                         bound of |det| from the orientations below it): same result as the loop;
+ *   WBRT_MESH_BVH_CAPPED  opt-in: the walk on plain surface-area trees with every margin capped at
+ *                         2e-4 of the ray's distance to the mesh (about 1.6x faster on the f1_car
+ *                         scene).  NOT proven equal to the loop: it can differ for a ray within about
+ *                         half a degree of a triangle's plane that passes that triangle at more than
+ *                         the margin, where the reference's own accept/reject decision is rounding
+ *                         noise.
  * In both BVH modes scenes with 48 or more bounding boxes find the boxes a ray enters through a
  * hierarchy over the boxes (conservative above, the reference's slab test gpu_kernel.cl:534-555 at
  * the leaves: the same boxes as its loop), and scenes with 48 or more spheres also walk a hierarchy over the spheres
  * (margins proven from the reference's float sphere test: same result as its loop over all
- * spheres, gpu_kernel.cl:361-371); WBRT_MESH_LOOP loops over all spheres as well.  In strict
- * mode meshes of at most 4096 triangles use the loop.
+ * spheres, gpu_kernel.cl:361-371); WBRT_MESH_LOOP loops over all spheres as well.  In WBRT_MESH_BVH
+ * meshes of at most 4096 triangles use the loop.
  * Primary ids and event counters always use the loops.  Takes effect at the next render. */
-enum { WBRT_MESH_LOOP = 0, WBRT_MESH_BVH_STRICT = 1, WBRT_MESH_BVH = 2 };
+enum { WBRT_MESH_LOOP = 0, WBRT_MESH_BVH = 1, WBRT_MESH_BVH_CAPPED = 2 };
 int wbrt_set_mesh_mode(wbrt_context *ctx, int mode);
 
 /* Launch schedule.  Waves are launched costliest pixel streams first.  The costs come from the

@@ -88,7 +88,7 @@ def build(force=False):
 
 
 _lib = None
-MESH_LOOP, MESH_BVH_STRICT, MESH_BVH = 0, 1, 2
+MESH_LOOP, MESH_BVH, MESH_BVH_CAPPED = 0, 1, 2
 
 # name -> (restype, argtypes); every symbol declared in include/ocl_rt_amd.h
 _P = C.c_void_p
@@ -435,7 +435,7 @@ class Context:
         _check(lib().wbrt_synchronize(self._h))
 
     def set_mesh_mode(self, mode):
-        """MESH_LOOP, MESH_BVH_STRICT or MESH_BVH (default); see include/ocl_rt_amd.h."""
+        """MESH_LOOP, MESH_BVH (default, proven equal to the loop) or MESH_BVH_CAPPED; see include/ocl_rt_amd.h."""
         _check(lib().wbrt_set_mesh_mode(self._h, int(mode)))
 
     def set_schedule_reuse(self, on=True):

@@ -462,7 +462,7 @@ void wbrt_build_bvh(const float4 *tri_geom, const int2 *ranges, int B, bool spli
 			for (const Prim &p : mbld.prims) for (int a = 0; a < 3; ++a) if (p.b.mn[a] > -DBL_MAX / 2 && p.b.mx[a] < DBL_MAX / 2) { all.mn[a] = std::min(all.mn[a], p.b.mn[a]); all.mx[a] = std::max(all.mx[a], p.b.mx[a]); }
 			double diag = 0.0;
 			for (int a = 0; a < 3; ++a) if (all.mx[a] > all.mn[a]) diag += (all.mx[a] - all.mn[a]) * (all.mx[a] - all.mn[a]);
-			mbld.rd = 4.0 * std::sqrt(diag) + 1e-30;
+			mbld.rd = 2.0 * std::sqrt(diag) + 1e-30;
 			Bounds rb;
 			MBounds rm;
 			double re;

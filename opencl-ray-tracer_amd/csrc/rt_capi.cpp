@@ -86,7 +86,7 @@ struct wbrt_context
 	int mesh_mode = WBRT_MESH_BVH;
 	int bvh_steal_min_idle = 8;
 	int strict_loop_max = 4096;   // proven-margin mode: meshes up to this many triangles use the cooperative loop
-	float bvh_rho = 2e-4f; // WBRT_MESH_BVH: box margin as a fraction of the ray's distance bound
+	float bvh_rho = 2e-4f; // WBRT_MESH_BVH_CAPPED: box margin as a fraction of the ray's distance bound
 	DevBuf sky, seeds, image, ids, counters, rgb8, costs, tile_costs, order, hist;
 	int lpt = 1;        // longest-first scheduling from a pilot pass
 	int pilot_spp = 4;
@@ -156,10 +156,10 @@ int make_params(wbrt_context *ctx, const wbrt_camera *cam, bool whole_frame, Ren
 	p.seeds = (const uint32_t *)ctx->seeds.p;
 	p.sc = ctx->sc;
 	// strict margins on a small mesh widen every box to the whole mesh: the cooperative loop is faster there
-	const bool strict_small = ctx->mesh_mode == WBRT_MESH_BVH_STRICT && ctx->sc.T <= ctx->strict_loop_max && !ctx->have_sphere_tree;
+	const bool strict_small = ctx->mesh_mode == WBRT_MESH_BVH && ctx->sc.T <= ctx->strict_loop_max && !ctx->have_sphere_tree;
 	if (ctx->mesh_mode != WBRT_MESH_LOOP && ctx->have_bvh && !strict_small)
 	{
-		const int variant = ctx->mesh_mode == WBRT_MESH_BVH_STRICT ? 1 : 0;
+		const int variant = ctx->mesh_mode == WBRT_MESH_BVH ? 1 : 0;
 		p.sc.bvh_nodes = ctx->bvh_ptr[variant][0];
 		p.sc.bvh_tris = ctx->bvh_ptr[variant][1];
 		p.sc.bvh_roots = ctx->bvh_ptr[variant][2];
@@ -174,7 +174,7 @@ int make_params(wbrt_context *ctx, const wbrt_camera *cam, bool whole_frame, Ren
 		}
 		p.sc.sph_tree = ctx->have_sphere_tree ? 1 : 0;
 	}
-	p.sc.bvh_rho = ctx->mesh_mode == WBRT_MESH_BVH ? ctx->bvh_rho : 0.0f;
+	p.sc.bvh_rho = ctx->mesh_mode == WBRT_MESH_BVH_CAPPED ? ctx->bvh_rho : 0.0f;
 	p.sc.bvh_steal_min_idle = ctx->bvh_steal_min_idle;
 	return WBRT_OK;
 }
@@ -683,7 +683,7 @@ int wbrt_set_schedule_reuse(wbrt_context *ctx, int reuse)
 int wbrt_set_mesh_mode(wbrt_context *ctx, int mode)
 {
 	if (!ctx) return fail(WBRT_ERR_INVALID, "null context");
-	if (mode < WBRT_MESH_LOOP || mode > WBRT_MESH_BVH) return fail(WBRT_ERR_INVALID, "bad mesh mode");
+	if (mode < WBRT_MESH_LOOP || mode > WBRT_MESH_BVH_CAPPED) return fail(WBRT_ERR_INVALID, "bad mesh mode");
 	ctx->mesh_mode = mode;
 	return WBRT_OK;
 }

@@ -677,15 +677,16 @@ __device__ __forceinline__ float mbox_lower(unsigned lo3, unsigned hi3, F3 d, F3
 //   |det| >= |e0||e1| (L - 6u|d|),  L = mbox_lower(child, d)     ->  K/|det| <= 1.02 |d| / L  once L > 2e-5 |d|.
 // |s| <= distance from o to the far corner of the child's box.  Constants: 26.5 u x 1.25 = 2.0e-6 (the factor covers
 // the second-order terms and the roundings of this function itself).
-__device__ __forceinline__ float strict_pad(float ox, float oy, float oz, F3 d, F3 dk, float dlen, float e_limit, float slop0,
-                                            float mnx, float mny, float mnz, float mxx, float mxy, float mxz, float E, unsigned lo3, unsigned hi3)
+__device__ __forceinline__ float far_corner(float ox, float oy, float oz, float mnx, float mny, float mnz, float mxx, float mxy, float mxz)
 {
 	const float fx = fmaxf(fabsf(mnx - ox), fabsf(mxx - ox)), fy = fmaxf(fabsf(mny - oy), fabsf(mxy - oy)), fz = fmaxf(fabsf(mnz - oz), fabsf(mxz - oz));
-	const float far = __builtin_amdgcn_sqrtf(__builtin_fmaf(fx, fx, __builtin_fmaf(fy, fy, fz * fz))) * 1.00001f;
+	return __builtin_amdgcn_sqrtf(__builtin_fmaf(fx, fx, __builtin_fmaf(fy, fy, fz * fz))) * 1.00001f;
+}
+// the det bound's factor of one child, or +inf when its m-box gives none
+__device__ __forceinline__ float det_factor(unsigned lo3, unsigned hi3, F3 d, F3 dk, float dlen)
+{
 	const float L = mbox_lower(lo3, hi3, d, dk) - 2e-6f * dlen;
-	const float by_e = E <= e_limit ? 0.20f * E : INFINITY;
-	const float by_det = L > 2e-5f * dlen ? 2.05e-6f * __builtin_amdgcn_rcpf(L) : INFINITY;
-	return __builtin_fmaf(fminf(by_e, by_det), far * dlen, __builtin_fmaf(3e-6f, far, slop0));
+	return L > 2e-5f * dlen ? 2.05e-6f * __builtin_amdgcn_rcpf(L) : INFINITY;
 }
 
 // margins of ray r against the hierarchy of `box`; returns its root reference (INT_MIN: no triangles)
@@ -901,10 +902,19 @@ __device__ __forceinline__ void triangles_steal(const SceneDev &sc, int (*stack)
 					}
 					else
 					{
-						const uint4 mq = sc.bvh_mbox[node];
-						const F3 dk = r.d * (1.0f / 127.0f);
-						pad_l = strict_pad(r.o.x, r.o.y, r.o.z, r.d, dk, r.dlen, r.e_limit, r.slop, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q3.z, mq.x, mq.y);
-						pad_r = strict_pad(r.o.x, r.o.y, r.o.z, r.d, dk, r.dlen, r.e_limit, r.slop, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.w, mq.z, mq.w);
+						const float far_l = far_corner(r.o.x, r.o.y, r.o.z, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
+						const float far_r = far_corner(r.o.x, r.o.y, r.o.z, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w);
+						float f_l = q3.z <= r.e_limit ? 0.20f * q3.z : INFINITY, f_r = q3.w <= r.e_limit ? 0.20f * q3.w : INFINITY;
+						// the determinant bound is worth its arithmetic only where the cutoff bound is not already tiny
+						if (__ballot(fmaxf(f_l, f_r) * r.dlen > 1e-4f))
+						{
+							const uint4 mq = sc.bvh_mbox[node];
+							const F3 dk = r.d * (1.0f / 127.0f);
+							f_l = fminf(f_l, det_factor(mq.x, mq.y, r.d, dk, r.dlen));
+							f_r = fminf(f_r, det_factor(mq.z, mq.w, r.d, dk, r.dlen));
+						}
+						pad_l = __builtin_fmaf(f_l, far_l * r.dlen, __builtin_fmaf(3e-6f, far_l, r.slop));
+						pad_r = __builtin_fmaf(f_r, far_r * r.dlen, __builtin_fmaf(3e-6f, far_r, r.slop));
 					}
 					vl = bvh_box(f3(r.o.x + pad_l, r.o.y + pad_l, r.o.z + pad_l), f3(r.o.x - pad_l, r.o.y - pad_l, r.o.z - pad_l), r.inv,
 					             q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, best, lo_l);

@@ -14,7 +14,7 @@ bw, bh = pkg.set_blocks(cam, 4)
 seeds = pkg.make_seeds(bw * bh, seed)
 imgs = {}
 ctx = pkg.Context(0); ctx.upload_scene(scene); ctx.upload_seeds(seeds)
-for mode in (pkg.MESH_BVH, pkg.MESH_BVH_STRICT, pkg.MESH_LOOP):
+for mode in (pkg.MESH_BVH_CAPPED, pkg.MESH_BVH, pkg.MESH_LOOP):
     ctx.set_mesh_mode(mode)
     img = ctx.render_frame(cam)
     ctx.set_timing(True)
@@ -27,7 +27,7 @@ for mode in (pkg.MESH_BVH, pkg.MESH_BVH_STRICT, pkg.MESH_LOOP):
     ctx.set_timing(False)
 ctx.close()
 ok = True
-for mode in (pkg.MESH_BVH, pkg.MESH_BVH_STRICT):
+for mode in (pkg.MESH_BVH_CAPPED, pkg.MESH_BVH):
     diff = int((bits(imgs[mode]) != bits(imgs[pkg.MESH_LOOP])).sum())
     print("mode %d vs loop: differing floats: %d of %d" % (mode, diff, imgs[mode].size))
     ok = ok and diff == 0

@@ -232,14 +232,14 @@ static int walk(const WbrtBvh &bvh, int variant, const Ray &r, int mode, float r
 					// the builder's own m-boxes; R = distance to the far corner of the child's box only
 					const float fl_ = far2(r.o, n.lmin, n.lmax), fr_ = far2(r.o, n.rmin, n.rmax);
 					const float sl = 3e-6f * (fl_ + std::fabs(r.o.x) + std::fabs(r.o.y) + std::fabs(r.o.z)), sr = 3e-6f * (fr_ + std::fabs(r.o.x) + std::fabs(r.o.y) + std::fabs(r.o.z));
-					pl = n.le <= e_limit ? 0.35f * n.le * fl_ * dlen + sl : INFINITY;
-					pr = n.re <= e_limit ? 0.35f * n.re * fr_ * dlen + sr : INFINITY;
+					pl = n.le <= e_limit ? 0.20f * n.le * fl_ * dlen + sl : INFINITY;
+					pr = n.re <= e_limit ? 0.20f * n.re * fr_ * dlen + sr : INFINITY;
 					MBox bl, br;
 					const float *mb = &bvh.mbox[12 * (size_t)node];
 					for (int a = 0; a < 3; ++a) { bl.lo[a] = mb[a]; bl.hi[a] = mb[3 + a]; br.lo[a] = mb[6 + a]; br.hi[a] = mb[9 + a]; }
 					const float lbl = mbox_lb(bl, r.d) - 1e-6f * dlen, lbr = mbox_lb(br, r.d) - 1e-6f * dlen;
-					if (lbl > 2e-5f * dlen) pl = std::fmin(pl, 3.5e-6f * fl_ * dlen / lbl + sl);
-					if (lbr > 2e-5f * dlen) pr = std::fmin(pr, 3.5e-6f * fr_ * dlen / lbr + sr);
+					if (lbl > 2e-5f * dlen) pl = std::fmin(pl, 2.05e-6f * fl_ * dlen / lbl + sl);
+					if (lbr > 2e-5f * dlen) pr = std::fmin(pr, 2.05e-6f * fr_ * dlen / lbr + sr);
 				}
 				if (mode == 3)
 				{

@@ -8,7 +8,7 @@ cam = pkg.camera_main_cpp(W, SPP, 50)
 bw, bh = pkg.set_blocks(cam, 4)
 ctx = pkg.Context(0); ctx.tune("strict_loop_max", loop_max); ctx.upload_scene(scene); ctx.upload_seeds(pkg.make_seeds(bw * bh, 11))
 imgs = {}
-for mode in (pkg.MESH_BVH, pkg.MESH_BVH_STRICT):
+for mode in (pkg.MESH_BVH_CAPPED, pkg.MESH_BVH):
     ctx.set_mesh_mode(mode)
     ctx.render_frame(cam)
     ctx.render_frame(cam)
@@ -18,5 +18,5 @@ for mode in (pkg.MESH_BVH, pkg.MESH_BVH_STRICT):
     ms, n = ctx.get_timing()
     ctx.set_timing(False)
     print("mode=%d %s %dx%d %d spp loop_max=%d: kernel %.2f ms per frame" % (mode, mesh, cam.width, cam.height, SPP, loop_max, ms / n), flush=True)
-print("identical:", (bits(imgs[pkg.MESH_BVH]) == bits(imgs[pkg.MESH_BVH_STRICT])).all())
+print("identical:", (bits(imgs[pkg.MESH_BVH_CAPPED]) == bits(imgs[pkg.MESH_BVH])).all())
 ctx.close()

@@ -186,30 +186,31 @@ def _many_boxes_scene():
 
 @pytest.mark.parametrize("name", ["awkward", "many_boxes", "f1_car", "stress"])
 def test_mesh_modes_identical(gpu_ctx, name):
-    """The hierarchy walks (strict and default margins) must reproduce the per-box triangle loop,
-    and the loop must reproduce the oracle."""
+    """The hierarchy walks (proven margins = the default, and the capped opt-in) must reproduce the per-box
+    triangle loop, and the loop must reproduce the oracle (f1_car: at a size the oracle's triangle loop finishes)."""
+    oracle_cam = None
     if name == "awkward":
-        scene, cam, check_oracle = _awkward_mesh_scene(), pkg.camera_main_cpp(192, 6, 50), True
+        scene, cam = _awkward_mesh_scene(), pkg.camera_main_cpp(192, 6, 50)
     elif name == "many_boxes":
-        scene, cam, check_oracle = _many_boxes_scene(), pkg.camera_main_cpp(160, 4, 50), True
+        scene, cam = _many_boxes_scene(), pkg.camera_main_cpp(160, 4, 50)
     elif name == "f1_car":
-        scene, cam, check_oracle = scene_main_cpp_with_mesh("f1_car"), pkg.camera_main_cpp(320, 6, 50), False
+        scene, cam, oracle_cam = scene_main_cpp_with_mesh("f1_car"), pkg.camera_main_cpp(320, 6, 50), pkg.camera_main_cpp(128, 4, 50)
     else:
-        scene, cam, check_oracle = pkg.scene_stress(60, 48, 48, 6, 6), pkg.camera_stress(256, 4, 50), False
-    seeds = _setup(gpu_ctx, scene, cam, 4, 21)
-    try:
-        images = {}
-        for mode in (pkg.MESH_LOOP, pkg.MESH_BVH_STRICT, pkg.MESH_BVH):
-            gpu_ctx.set_mesh_mode(mode)
-            images[mode] = gpu_ctx.render_frame(cam)
-    finally:
-        gpu_ctx.set_mesh_mode(pkg.MESH_BVH)
-    assert np.array_equal(bits(images[pkg.MESH_BVH_STRICT]), bits(images[pkg.MESH_LOOP]))
-    assert np.array_equal(bits(images[pkg.MESH_BVH]), bits(images[pkg.MESH_LOOP]))
-    if check_oracle:
-        O = orc.Oracle(scene)
-        assert np.array_equal(bits(images[pkg.MESH_LOOP]), bits(O.render_frame(cam, seeds)))
-        assert np.array_equal(gpu_ctx.primary_ids(cam), O.primary_ids(cam, seeds))
+        scene, cam = pkg.scene_stress(60, 48, 48, 6, 6), pkg.camera_stress(256, 4, 50)
+    for c in ([cam, oracle_cam] if oracle_cam is not None else [cam]):
+        seeds = _setup(gpu_ctx, scene, c, 4, 21)
+        try:
+            images = {}
+            for mode in (pkg.MESH_LOOP, pkg.MESH_BVH, pkg.MESH_BVH_CAPPED):
+                gpu_ctx.set_mesh_mode(mode)
+                images[mode] = gpu_ctx.render_frame(c)
+        finally:
+            gpu_ctx.set_mesh_mode(pkg.MESH_BVH)
+        assert np.array_equal(bits(images[pkg.MESH_BVH]), bits(images[pkg.MESH_LOOP]))
+        assert np.array_equal(bits(images[pkg.MESH_BVH_CAPPED]), bits(images[pkg.MESH_LOOP]))
+    O = orc.Oracle(scene)
+    assert np.array_equal(bits(images[pkg.MESH_LOOP]), bits(O.render_frame(c, seeds, threads=16)))
+    assert np.array_equal(gpu_ctx.primary_ids(c), O.primary_ids(c, seeds))
 
 
 def test_mesh_goldens_at_size(gpu_ctx):
@@ -223,7 +224,7 @@ def test_mesh_goldens_at_size(gpu_ctx):
     _setup(gpu_ctx, scene, cam, meta["blocks"], meta["seed"])
     assert np.array_equal(gpu_ctx.primary_ids(cam), z["ids"])
     try:
-        for mode in (pkg.MESH_LOOP, pkg.MESH_BVH_STRICT, pkg.MESH_BVH):
+        for mode in (pkg.MESH_LOOP, pkg.MESH_BVH, pkg.MESH_BVH_CAPPED):
             gpu_ctx.set_mesh_mode(mode)
             mae, psnr = image_error(gpu_ctx.render_frame(cam), z["image"])
             assert mae <= 1e-3 and psnr >= 40.0, (mode, mae, psnr)
@@ -261,9 +262,9 @@ def test_many_spheres_walk_equals_loop_and_oracle(gpu_ctx, case):
     cam = pkg.camera_stress(width, spp, 50)
     seeds = _setup(gpu_ctx, scene, cam, 4, 31)
     try:
-        gpu_ctx.set_mesh_mode(pkg.MESH_BVH)
+        gpu_ctx.set_mesh_mode(pkg.MESH_BVH_CAPPED)
         walk = gpu_ctx.render_frame(cam)
-        gpu_ctx.set_mesh_mode(pkg.MESH_BVH_STRICT)
+        gpu_ctx.set_mesh_mode(pkg.MESH_BVH)
         strict = gpu_ctx.render_frame(cam)
         gpu_ctx.set_mesh_mode(pkg.MESH_LOOP)
         loop = gpu_ctx.render_frame(cam)
@@ -459,12 +460,12 @@ def test_stress_config_full_resolution(gpu_ctx):
     scene, cam = pkg.scene_stress(500, 224, 224, 16, 16), pkg.camera_stress(3840, 2, 50)
     seeds = _setup(gpu_ctx, scene, cam, 4, 77)
     images = {}
-    for mode in (pkg.MESH_BVH, pkg.MESH_BVH_STRICT, pkg.MESH_LOOP):
+    for mode in (pkg.MESH_BVH_CAPPED, pkg.MESH_BVH, pkg.MESH_LOOP):
         gpu_ctx.set_mesh_mode(mode)
         images[mode] = gpu_ctx.render_frame(cam)
     gpu_ctx.set_mesh_mode(pkg.MESH_BVH)
-    assert np.array_equal(bits(images[pkg.MESH_BVH_STRICT]), bits(images[pkg.MESH_LOOP]))
     assert np.array_equal(bits(images[pkg.MESH_BVH]), bits(images[pkg.MESH_LOOP]))
+    assert np.array_equal(bits(images[pkg.MESH_BVH_CAPPED]), bits(images[pkg.MESH_LOOP]))
     ids = gpu_ctx.primary_ids(cam)
     assert ids.min() >= -1 and ids.max() < scene.S + scene.T
     # oracle on a strip of one block: image and primary ids
@@ -588,13 +589,13 @@ def test_random_mesh_scenes(gpu_ctx, seed):
     seeds = _setup(gpu_ctx, scene, cam, 4, 600 + seed)
     try:
         images = {}
-        for mode in (pkg.MESH_LOOP, pkg.MESH_BVH_STRICT, pkg.MESH_BVH):
+        for mode in (pkg.MESH_LOOP, pkg.MESH_BVH, pkg.MESH_BVH_CAPPED):
             gpu_ctx.set_mesh_mode(mode)
             images[mode] = gpu_ctx.render_frame(cam)
     finally:
         gpu_ctx.set_mesh_mode(pkg.MESH_BVH)
-    assert np.array_equal(bits(images[pkg.MESH_BVH_STRICT]), bits(images[pkg.MESH_LOOP]))
     assert np.array_equal(bits(images[pkg.MESH_BVH]), bits(images[pkg.MESH_LOOP]))
+    assert np.array_equal(bits(images[pkg.MESH_BVH_CAPPED]), bits(images[pkg.MESH_LOOP]))
     O = orc.Oracle(scene)
     assert np.array_equal(bits(images[pkg.MESH_LOOP]), bits(O.render_frame(cam, seeds)))
     assert np.array_equal(gpu_ctx.primary_ids(cam), O.primary_ids(cam, seeds))
@@ -616,12 +617,12 @@ def test_box_hierarchy_equals_box_loop(name):
         try:
             ctx.tune("box_tree_min", tree_min)
             seeds = _setup(ctx, scene, cam, 4, 21)
-            for mode in (pkg.MESH_BVH, pkg.MESH_BVH_STRICT):
+            for mode in (pkg.MESH_BVH_CAPPED, pkg.MESH_BVH):
                 ctx.set_mesh_mode(mode)
                 images[(tree_min, mode)] = ctx.render_frame(cam)
         finally:
             ctx.close()
-    ref = images[(1 << 30, pkg.MESH_BVH_STRICT)]
+    ref = images[(1 << 30, pkg.MESH_BVH)]
     for key, img in images.items():
         assert np.array_equal(bits(img), bits(ref)), key
     assert np.array_equal(bits(ref), bits(orc.Oracle(scene).render_frame(cam, seeds)))
