@@ -141,6 +141,50 @@ int wbrt_tonemap_device(wbrt_context *ctx, const void *device_image, float scale
 
 int wbrt_synchronize(wbrt_context *ctx);
 
+/* ------------------------------------------------ seed shards and multi-GPU (no counterpart in the reference,
+ * which drives one device: main.cpp:27-29,175).  The reference has ONE random stream per pixel with a data-dependent
+ * number of draws per sample (gpu_kernel.cl:606,624-645), so a frame is split into num_shards SEED SHARDS instead of
+ * sample ranges: shard v = the reference kernel's semantics with its own seed buffer wbrt_make_seeds(base_seed, v)
+ * and shard_spp[v] samples per pixel, output = the un-normalised clamped per-sample sum (gpu_kernel.cl:632-644 before
+ * :647).  frame = sum over shards / total samples.  The shard count is fixed per workload, independent of the GPU
+ * count, so the picture is the same on 1, 2, 4 or 8 GPUs (up to float summation order). */
+
+/* shard v belongs to rank v % world; writes the shards of `rank` (ascending), returns their count (-1: bad argument) */
+int32_t wbrt_shards_of_rank(int32_t num_shards, int32_t rank, int32_t world, int32_t *shards);
+/* samples per shard for total_spp samples: the first total_spp % num_shards shards take one more */
+int32_t wbrt_split_spp(int32_t total_spp, int32_t num_shards, int32_t *shard_spp);
+
+/* wbrt_make_seeds + wbrt_upload_seeds without the host: the n seeds of (base_seed, shard) are generated on the
+ * device into the context's seed buffer, on `stream` (bit-identical to wbrt_make_seeds).  Replaces main.cpp:148-152
+ * + :166,183 for shard renders. */
+int wbrt_make_seeds_device(wbrt_context *ctx, uint64_t base_seed, uint32_t shard, size_t n, void *stream);
+
+/* Renders the shards of `rank` (of `world`) of one frame into device_image (width*height*3 floats, zeroed by the
+ * call, then += every shard's clamped sum), all on `stream`, asynchronously, without host synchronisation: seeds are
+ * generated on the device.  shard_spp: samples per shard (num_shards entries), or NULL = camera->samplesPerPixel each.
+ * With world > 1 the caller sums device_image over the ranks afterwards (wbrt_comm_allreduce_sum, or a collective of
+ * its own when every rank is a process). */
+int wbrt_render_shards(wbrt_context *ctx, const wbrt_camera *camera, int32_t num_shards, const int32_t *shard_spp,
+                       uint64_t base_seed, int32_t rank, int32_t world, void *device_image, void *stream);
+
+/* One process, n GPUs: a communicator over RCCL (ncclCommInitAll; xGMI between the GPUs of a node).  devices: the HIP
+ * ordinals, each once.  n == 1 needs no RCCL.  WBRT_ERR_NO_DEVICE when RCCL cannot be loaded. */
+typedef struct wbrt_comm wbrt_comm;
+int wbrt_comm_create(const int32_t *devices, int32_t n, wbrt_comm **out);
+int wbrt_comm_destroy(wbrt_comm *comm);
+int32_t wbrt_comm_size(const wbrt_comm *comm);
+/* In-place all-reduce(sum) of n float buffers of `count` elements, buffer i on device i of the communicator, enqueued
+ * on streams[i] (NULL array = default streams): the exchange step of a sharded frame, once per frame
+ * (count = width*height*3: 11.06 MB at 1280x720).  Asynchronous. */
+int wbrt_comm_allreduce_sum(wbrt_comm *comm, void *const *device_buffers, size_t count, void *const *streams);
+/* One sharded frame on n GPUs driven by this thread (replaces the block loop main.cpp:229-247 for multi-GPU hosts):
+ * context i (on device i of the communicator) renders the shards v % n == i into its own device buffer, all GPUs
+ * concurrently; one all-reduce(sum); host_sum (width*height*3 floats, row 0 = bottom) receives the frame's clamped
+ * per-sample SUM over all shards (divide by the total sample count for the picture).  Blocking.  comm may be NULL
+ * when n == 1.  Every context must hold the scene and the sky. */
+int wbrt_render_sharded_frame(wbrt_comm *comm, wbrt_context *const *ctxs, int32_t n, const wbrt_camera *camera,
+                              int32_t num_shards, const int32_t *shard_spp, uint64_t base_seed, float *host_sum);
+
 /* How the render kernel finds the nearest triangle of a bounding box whose slab test
  * passed (gpu_kernel.cl:374-391).  No counterpart in the reference, which always loops.
  *   WBRT_MESH_LOOP        every triangle of the box is tested, as the reference does;

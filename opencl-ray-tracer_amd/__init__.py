@@ -107,6 +107,15 @@ _SIGNATURES = {
     "wbrt_count_events_frame": (C.c_int, [_P, C.POINTER(Camera), _P]),
     "wbrt_tonemap_device": (C.c_int, [_P, _P, C.c_float, C.c_int32, C.c_int32, _P, _P]),
     "wbrt_synchronize": (C.c_int, [_P]),
+    "wbrt_shards_of_rank": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, _P]),
+    "wbrt_split_spp": (C.c_int32, [C.c_int32, C.c_int32, _P]),
+    "wbrt_make_seeds_device": (C.c_int, [_P, C.c_uint64, C.c_uint32, C.c_size_t, _P]),
+    "wbrt_render_shards": (C.c_int, [_P, C.POINTER(Camera), C.c_int32, _P, C.c_uint64, C.c_int32, C.c_int32, _P, _P]),
+    "wbrt_comm_create": (C.c_int, [_P, C.c_int32, C.POINTER(_P)]),
+    "wbrt_comm_destroy": (C.c_int, [_P]),
+    "wbrt_comm_size": (C.c_int32, [_P]),
+    "wbrt_comm_allreduce_sum": (C.c_int, [_P, _P, C.c_size_t, _P]),
+    "wbrt_render_sharded_frame": (C.c_int, [_P, _P, C.c_int32, C.POINTER(Camera), C.c_int32, _P, C.c_uint64, _P]),
     "wbrt_set_mesh_mode": (C.c_int, [_P, C.c_int]),
     "wbrt_set_schedule_reuse": (C.c_int, [_P, C.c_int]),
     "wbrt_set_timing": (C.c_int, [_P, C.c_int]),
@@ -417,6 +426,18 @@ class Context:
         """Private test/experiment hook (wbrt_tune_): thresholds that never change a result."""
         _check(lib().wbrt_tune_(self._h, key.encode(), int(value)))
 
+    def make_seeds_device(self, n, base_seed=0x5EED, shard=0, stream=None):
+        """Generates the seed buffer of (base_seed, shard) on the device (== make_seeds + upload_seeds, no host copy)."""
+        _check(lib().wbrt_make_seeds_device(self._h, base_seed, shard, n, C.c_void_p(stream) if stream else None))
+
+    def render_shards(self, cam, device_ptr, num_shards, base_seed=0x5EED, rank=0, world=1, shard_spp=None, stream=None):
+        """This rank's seed shards of one frame summed into device_ptr (zeroed first); asynchronous on `stream`."""
+        arr = None if shard_spp is None else np.ascontiguousarray(shard_spp, dtype=np.int32)
+        if arr is not None and arr.size != num_shards:
+            raise ValueError("shard_spp needs one entry per shard")
+        _check(lib().wbrt_render_shards(self._h, C.byref(cam), num_shards, _ptr(arr), base_seed, rank, world,
+                                        C.c_void_p(device_ptr), C.c_void_p(stream) if stream else None))
+
     def primary_ids(self, cam):
         out = np.empty((cam.height, cam.width), dtype=np.int32)
         _check(lib().wbrt_primary_ids_frame(self._h, C.byref(cam), _ptr(out)))
@@ -461,6 +482,53 @@ class Context:
         out = np.empty_like(a)
         _check(lib().wbrt_math_probe_(self._h, op, _ptr(a), _ptr(b), _ptr(out), a.size))
         return out
+
+
+def shards_of_rank(num_shards, rank, world):
+    out = np.empty(max(num_shards, 1), dtype=np.int32)
+    n = lib().wbrt_shards_of_rank(num_shards, rank, world, _ptr(out))
+    if n < 0:
+        raise ValueError("bad shard split")
+    return [int(v) for v in out[:n]]
+
+
+def split_spp(total_spp, num_shards):
+    out = np.empty(num_shards, dtype=np.int32)
+    if lib().wbrt_split_spp(total_spp, num_shards, _ptr(out)) != 0:
+        raise ValueError("bad shard split")
+    return [int(v) for v in out]
+
+
+def render_sharded_frame(ctxs, cam, num_shards, base_seed=0x5EED, shard_spp=None, comm=None):
+    """wbrt_render_sharded_frame: one frame of num_shards seed shards over the given contexts (one per GPU); returns
+    the clamped per-sample sum over all shards as a host array."""
+    out = np.empty((cam.height, cam.width, 3), dtype=np.float32)
+    arr = None if shard_spp is None else np.ascontiguousarray(shard_spp, dtype=np.int32)
+    hs = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    _check(lib().wbrt_render_sharded_frame(comm._h if comm is not None else None, hs, len(ctxs), C.byref(cam), num_shards,
+                                           _ptr(arr), base_seed, _ptr(out)))
+    return out
+
+
+class Comm:
+    """One process, several GPUs: RCCL communicator of the C ABI (wbrt_comm_*)."""
+
+    def __init__(self, devices):
+        arr = np.ascontiguousarray(devices, dtype=np.int32)
+        h = C.c_void_p()
+        _check(lib().wbrt_comm_create(_ptr(arr), arr.size, C.byref(h)))
+        self._h = h
+        self.size = arr.size
+
+    def allreduce_sum(self, device_ptrs, count, streams=None):
+        bufs = (C.c_void_p * self.size)(*[C.c_void_p(p) for p in device_ptrs])
+        st = None if streams is None else (C.c_void_p * self.size)(*[C.c_void_p(x) if x else None for x in streams])
+        _check(lib().wbrt_comm_allreduce_sum(self._h, bufs, count, st))
+
+    def close(self):
+        if self._h:
+            lib().wbrt_comm_destroy(self._h)
+            self._h = None
 
 
 # ------------------------------------------------------------ FLOP accounting

@@ -13,6 +13,7 @@
 #include <vector>
 
 void wbrt_set_error_(const char *msg);
+extern "C" uint64_t wbrt_seed_stream_state_(uint64_t base_seed, uint32_t shard);
 
 namespace {
 
@@ -101,8 +102,8 @@ struct wbrt_context
 	bool timing = false;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> events; // pool; the first events_used pairs hold launches
 	size_t events_used = 0;
-	hipEvent_t schedule_done = nullptr; // recorded after every launch that used the context's schedule arrays
-	bool schedule_busy = false;
+	hipEvent_t render_done = nullptr; // recorded after every render launch: the launch's use of the context's buffers ends there
+	bool render_busy = false;
 	int arith_mode = 0;
 };
 
@@ -112,6 +113,16 @@ int bind(wbrt_context *ctx)
 {
 	if (!ctx) return fail(WBRT_ERR_INVALID, "null context");
 	HIP_TRY(hipSetDevice(ctx->device));
+	return WBRT_OK;
+}
+
+// Uploads replace buffers a render launch of this context may still read: wait for that launch only (other
+// contexts and streams of the device keep running).
+int wait_renders(wbrt_context *ctx)
+{
+	if (ctx->render_busy) HIP_TRY(hipEventSynchronize(ctx->render_done));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	ctx->render_busy = false;
 	return WBRT_OK;
 }
 
@@ -229,7 +240,7 @@ int scheduled_launch(wbrt_context *ctx, const RenderParams &p, hipStream_t strea
 			s.tile_costs = (int *)ctx->tile_costs.p; s.hist = (unsigned *)ctx->hist.p;
 			// the arrays are shared by every launch of this context: a launch on another stream waits until
 			// the previous launch has finished with them
-			if (ctx->schedule_busy) HIP_TRY(hipStreamWaitEvent(stream, ctx->schedule_done, 0));
+			if (ctx->render_busy) HIP_TRY(hipStreamWaitEvent(stream, ctx->render_done, 0));
 		}
 		// The full launch records the exact counts of every pixel stream; while the view (camera,
 		// tiling, depth, scene, mesh mode) stays the same they price the next launch, whatever its
@@ -265,13 +276,10 @@ int scheduled_launch(wbrt_context *ctx, const RenderParams &p, hipStream_t strea
 			ctx->recorded_spp = p.spp;
 		}
 		HIP_TRY(wbrt_launch_render(q, stream));
-		if (!fixed)
-		{
-			HIP_TRY(hipEventRecord(ctx->schedule_done, stream));
-			ctx->schedule_busy = true;
-		}
 	}
 	else HIP_TRY(wbrt_launch_render(q, stream));
+	HIP_TRY(hipEventRecord(ctx->render_done, stream));
+	ctx->render_busy = true;
 	if (timing) return timing_end(ctx, stream);
 	return WBRT_OK;
 }
@@ -302,13 +310,13 @@ int wbrt_create(int device_ordinal, wbrt_context **out)
 	ctx->device = device_ordinal;
 	e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
 	if (e != hipSuccess) { delete ctx; return fail(WBRT_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorName(e)); }
-	e = hipEventCreateWithFlags(&ctx->schedule_done, hipEventDisableTiming);
+	e = hipEventCreateWithFlags(&ctx->render_done, hipEventDisableTiming);
 	if (e != hipSuccess) { (void)hipStreamDestroy(ctx->stream); delete ctx; return fail(WBRT_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorName(e)); }
 	// this device's copy of the static schedule array (wbrt_render_frame_device_noalloc)
 	e = wbrt_scratch_init(device_ordinal);
 	if (e != hipSuccess)
 	{
-		(void)hipEventDestroy(ctx->schedule_done); (void)hipStreamDestroy(ctx->stream); delete ctx;
+		(void)hipEventDestroy(ctx->render_done); (void)hipStreamDestroy(ctx->stream); delete ctx;
 		return fail(WBRT_ERR_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorName(e));
 	}
 	*out = ctx;
@@ -321,7 +329,7 @@ int wbrt_destroy(wbrt_context *ctx)
 	(void)hipSetDevice(ctx->device);
 	(void)hipDeviceSynchronize();
 	for (auto &ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
-	if (ctx->schedule_done) (void)hipEventDestroy(ctx->schedule_done);
+	if (ctx->render_done) (void)hipEventDestroy(ctx->render_done);
 	DevBuf *all[] = { &ctx->sph_geom, &ctx->sph_radius, &ctx->sph_mat_a, &ctx->sph_mat_b, &ctx->tri_geom,
 	                  &ctx->tri_mat_a, &ctx->tri_mat_b, &ctx->tri_orig, &ctx->box_min, &ctx->box_max,
 	                  &ctx->box_range, &ctx->bvh_nodes[0], &ctx->bvh_tris[0], &ctx->bvh_roots[0],
@@ -340,7 +348,12 @@ int wbrt_upload_scene(wbrt_context *ctx, const wbrt_sphere *spheres, int32_t S,
 	if (rc) return rc;
 	if (S < 0 || T < 0 || B < 0) return fail(WBRT_ERR_INVALID, "negative primitive count");
 	if ((S && !spheres) || (T && !tris) || (B && !boxes)) return fail(WBRT_ERR_INVALID, "null primitive array");
-	HIP_TRY(hipDeviceSynchronize());
+	rc = wait_renders(ctx);
+	if (rc) return rc;
+	// until every buffer of the new scene is in place the context has no scene (a failed upload leaves it so)
+	ctx->have_scene = ctx->have_bvh = ctx->have_sphere_tree = false;
+	ctx->top_depth = 0;
+	ctx->recorded_spp = 0;
 
 	// spheres -> SoA; radius*radius is one rounding, as in gpu_kernel.cl:460
 	std::vector<float4> geom((size_t)S), mat_a((size_t)S);
@@ -522,7 +535,9 @@ int wbrt_upload_sky(wbrt_context *ctx, const wbrt_vec3 *texels, int32_t width, i
 	int rc = bind(ctx);
 	if (rc) return rc;
 	if (!texels || width <= 0 || height <= 0) return fail(WBRT_ERR_INVALID, "bad sky image");
-	HIP_TRY(hipDeviceSynchronize());
+	rc = wait_renders(ctx);
+	if (rc) return rc;
+	ctx->have_sky = false;
 	size_t n = (size_t)width * height, guard = (size_t)width + 1;
 	std::vector<float> buf((n + guard) * 3, 0.0f);
 	std::memcpy(buf.data(), texels, n * sizeof(wbrt_vec3));
@@ -539,10 +554,57 @@ int wbrt_upload_seeds(wbrt_context *ctx, const uint32_t *seeds, size_t n)
 	int rc = bind(ctx);
 	if (rc) return rc;
 	if (!seeds || !n) return fail(WBRT_ERR_INVALID, "empty seed buffer");
-	HIP_TRY(hipDeviceSynchronize());
+	rc = wait_renders(ctx);
+	if (rc) return rc;
+	ctx->n_seeds = 0;
 	rc = ctx->seeds.upload(seeds, n * sizeof(uint32_t));
 	if (rc) return rc;
 	ctx->n_seeds = n;
+	return WBRT_OK;
+}
+
+int wbrt_make_seeds_device(wbrt_context *ctx, uint64_t base_seed, uint32_t shard, size_t n, void *stream)
+{
+	int rc = bind(ctx);
+	if (rc) return rc;
+	if (!n || n > 0xFFFFFFFFull) return fail(WBRT_ERR_INVALID, "bad seed count");
+	if (n * sizeof(uint32_t) > ctx->seeds.bytes || !ctx->seeds.p)
+	{
+		// growing the buffer frees the old one: no launch may still read it
+		rc = wait_renders(ctx);
+		if (rc) return rc;
+		ctx->n_seeds = 0;
+		rc = ctx->seeds.reserve(n * sizeof(uint32_t));
+		if (rc) return rc;
+	}
+	// a launch of this context on ANOTHER stream may still read the buffer
+	if (ctx->render_busy) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, ctx->render_done, 0));
+	HIP_TRY(wbrt_launch_make_seeds(wbrt_seed_stream_state_(base_seed, shard), (uint32_t *)ctx->seeds.p, n, (hipStream_t)stream));
+	ctx->n_seeds = n;
+	return WBRT_OK;
+}
+
+int wbrt_render_shards(wbrt_context *ctx, const wbrt_camera *camera, int32_t num_shards, const int32_t *shard_spp, uint64_t base_seed,
+                       int32_t rank, int32_t world, void *device_image, void *stream)
+{
+	int rc = bind(ctx);
+	if (rc) return rc;
+	if (!camera || !device_image) return fail(WBRT_ERR_INVALID, "null argument");
+	if (num_shards <= 0 || world <= 0 || rank < 0 || rank >= world) return fail(WBRT_ERR_INVALID, "bad shard split");
+	if (camera->width <= 0 || camera->height <= 0 || camera->blockSize.x < 1.0f || camera->blockSize.y < 1.0f)
+		return fail(WBRT_ERR_INVALID, "bad camera");
+	const size_t bytes = (size_t)camera->width * camera->height * 3 * sizeof(float);
+	const size_t block_px = (size_t)(int)camera->blockSize.x * (size_t)(int)camera->blockSize.y;
+	HIP_TRY(hipMemsetAsync(device_image, 0, bytes, (hipStream_t)stream));
+	for (int32_t v = rank; v < num_shards; v += world)
+	{
+		wbrt_camera c = *camera;
+		if (shard_spp) c.samplesPerPixel = shard_spp[v];
+		rc = wbrt_make_seeds_device(ctx, base_seed, (uint32_t)v, block_px, stream);
+		if (rc) return rc;
+		rc = wbrt_render_frame_device(ctx, &c, WBRT_OUT_ACCUMULATE, device_image, stream);
+		if (rc) return rc;
+	}
 	return WBRT_OK;
 }
 
@@ -597,6 +659,44 @@ int wbrt_render_frame_device_noalloc(wbrt_context *ctx, const wbrt_camera *camer
 	p.out = (float *)device_image;
 	p.out_mode = out_mode;
 	return scheduled_launch(ctx, p, (hipStream_t)stream, &s);
+}
+
+int wbrt_render_sharded_frame(wbrt_comm *comm, wbrt_context *const *ctxs, int32_t n, const wbrt_camera *camera, int32_t num_shards,
+                              const int32_t *shard_spp, uint64_t base_seed, float *host_sum)
+{
+	if (!ctxs || n <= 0 || !camera || !host_sum) return fail(WBRT_ERR_INVALID, "null argument");
+	if (n > 1 && (!comm || wbrt_comm_size(comm) != n)) return fail(WBRT_ERR_INVALID, "communicator size does not match the contexts");
+	if (camera->width <= 0 || camera->height <= 0) return fail(WBRT_ERR_INVALID, "camera width/height must be positive");
+	const size_t count = (size_t)camera->width * camera->height * 3, bytes = count * sizeof(float);
+	std::vector<void *> images((size_t)n), streams((size_t)n);
+	// every GPU's shards are enqueued before any GPU is waited for: the GPUs render concurrently from this one thread
+	for (int32_t i = 0; i < n; ++i)
+	{
+		wbrt_context *ctx = ctxs[i];
+		int rc = bind(ctx);
+		if (rc) return rc;
+		rc = ctx->image.reserve(bytes);
+		if (rc) return rc;
+		images[(size_t)i] = ctx->image.p;
+		streams[(size_t)i] = ctx->stream;
+		rc = wbrt_render_shards(ctx, camera, num_shards, shard_spp, base_seed, i, n, ctx->image.p, ctx->stream);
+		if (rc) return rc;
+	}
+	if (n > 1)
+	{
+		int rc = wbrt_comm_allreduce_sum(comm, images.data(), count, streams.data());
+		if (rc) return rc;
+	}
+	int rc = bind(ctxs[0]);
+	if (rc) return rc;
+	HIP_TRY(hipMemcpyAsync(host_sum, images[0], bytes, hipMemcpyDeviceToHost, ctxs[0]->stream));
+	for (int32_t i = 0; i < n; ++i)
+	{
+		rc = bind(ctxs[i]);
+		if (rc) return rc;
+		HIP_TRY(hipStreamSynchronize(ctxs[i]->stream));
+	}
+	return WBRT_OK;
 }
 
 int wbrt_render_frame(wbrt_context *ctx, const wbrt_camera *camera, int out_mode, float *host_image)

@@ -142,6 +142,8 @@ hipError_t wbrt_launch_ids(const RenderParams &p, hipStream_t stream);
 // exact: the counts come from a full launch of the same view (not from a pilot launch)
 hipError_t wbrt_launch_cost_sort(const int *costs, const int *walk, int n, int pilot_spp, int exact, int *tile_costs, unsigned *hist, int *order, hipStream_t stream);
 hipError_t wbrt_launch_tonemap(const float *image, float scale, int width, int height, uint8_t *rgb8, hipStream_t stream);
+// seeds[i] = the i-th seed of the SplitMix64 stream that starts at state0 (see wbrt_make_seeds)
+hipError_t wbrt_launch_make_seeds(unsigned long long state0, uint32_t *seeds, size_t n, hipStream_t stream);
 // evaluates the device's float / double primitives on arrays (known-answer tests)
 hipError_t wbrt_launch_math_probe(int op, const float *a, const float *b, float *out, int n, hipStream_t stream);
 

@@ -1422,6 +1422,20 @@ __global__ void k_tonemap(const float *image, float scale, int width, int height
 	}
 }
 
+// Seed buffer of one shard, generated where it is used: the host generator (wbrt_make_seeds) draws from a SplitMix64
+// stream, whose i-th output depends only on state0 + (i+1) * golden, so every seed is computed independently here.
+__global__ void k_make_seeds(unsigned long long state0, uint32_t *seeds, unsigned n)
+{
+	const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	unsigned long long z = state0 + (unsigned long long)(i + 1u) * 0x9E3779B97F4A7C15ULL;
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+	z ^= z >> 31;
+	const unsigned long long r = z >> 33; // 31 bits, like a POSIX rand()
+	seeds[i] = (uint32_t)(r * 0x5DEECE66DULL + 0xBULL); // main.cpp:151: the low 32 bits
+}
+
 // op: 0 a/b, 1 sqrtf(a), 2 atan2(a,b), 3 asin(a), 4 a^5, 5 rng float of seed bits a (32-bit) after b draws,
 // 6 shared-reciprocal division a/b, 7/8 sky texel index (fast with fallback / exact), 9 division by a constant
 __global__ void k_math_probe(int op, const float *a, const float *b, float *out, int n)
@@ -1623,6 +1637,13 @@ hipError_t wbrt_launch_ids(const RenderParams &p, hipStream_t stream)
 hipError_t wbrt_launch_tonemap(const float *image, float scale, int width, int height, uint8_t *rgb8, hipStream_t stream)
 {
 	hipLaunchKernelGGL(k_tonemap, dim3(2048), dim3(256), 0, stream, image, scale, width, height, rgb8);
+	return hipGetLastError();
+}
+
+hipError_t wbrt_launch_make_seeds(unsigned long long state0, uint32_t *seeds, size_t n, hipStream_t stream)
+{
+	if (!n) return hipSuccess;
+	hipLaunchKernelGGL(k_make_seeds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, state0, seeds, (unsigned)n);
 	return hipGetLastError();
 }
 

@@ -133,14 +133,35 @@ wbrt_vec3 wbrt_ideal_block_size(int32_t width, int32_t height, int32_t target_bl
 // main.cpp:148-152 with rand() replaced by a SplitMix64 stream so renders are reproducible.
 // The reference's expression masks with 0xFFFFFFFF (>> binds tighter than &), i.e. it keeps
 // the low 32 bits of r*0x5DEECE66D + 0xB.
+uint64_t wbrt_seed_stream_state_(uint64_t base_seed, uint32_t shard) { return base_seed ^ (0xD1B54A32D192ED03ULL * (uint64_t)(shard + 1)); }
+
 void wbrt_make_seeds(uint64_t base_seed, uint32_t shard, uint32_t *seeds, size_t n)
 {
-	SplitMix64 g(base_seed ^ (0xD1B54A32D192ED03ULL * (uint64_t)(shard + 1)));
+	SplitMix64 g(wbrt_seed_stream_state_(base_seed, shard));
 	for (size_t i = 0; i < n; ++i)
 	{
 		uint64_t r = g.next() >> 33; // 31-bit, like a POSIX rand()
 		seeds[i] = (uint32_t)((r * 0x5DEECE66DULL + 0xBULL) & 0xFFFFFFFFULL);
 	}
+}
+
+// Seed shards of a frame (no counterpart in the reference, which has one device): shard v of num_shards belongs to
+// rank v % world; when total_spp is not a multiple of num_shards the first total_spp % num_shards shards take one
+// sample more.
+int32_t wbrt_shards_of_rank(int32_t num_shards, int32_t rank, int32_t world, int32_t *shards)
+{
+	if (num_shards < 0 || world <= 0 || rank < 0 || rank >= world) return -1;
+	int32_t n = 0;
+	for (int32_t v = rank; v < num_shards; v += world) { if (shards) shards[n] = v; ++n; }
+	return n;
+}
+
+int32_t wbrt_split_spp(int32_t total_spp, int32_t num_shards, int32_t *shard_spp)
+{
+	if (total_spp < 0 || num_shards <= 0 || !shard_spp) return -1;
+	const int32_t q = total_spp / num_shards, r = total_spp % num_shards;
+	for (int32_t v = 0; v < num_shards; ++v) shard_spp[v] = q + (v < r ? 1 : 0);
+	return 0;
 }
 
 // colour.cpp:5-15: sqrt is the C double function, so the product with 255.0f is formed in

@@ -18,6 +18,7 @@ static void usage()
 	std::printf(
 	    "wbrt_render [--scene readme|maincpp] [--width N] [--spp N] [--depth N] [--blocks N]\n"
 	    "            [--mesh file.obj] [--sky file.hdr] [--seed N] [--out name] [--whole-frame] [--device N]\n"
+	    "            [--gpus N --shards V]   the frame as V seed shards of spp/V samples split over N GPUs (RCCL all-reduce)\n"
 	    "  writes <name>.ppm (8-bit, gamma 2), <name>.pfm (linear float) and <name>.bmp\n");
 }
 
@@ -36,7 +37,7 @@ int main(int argc, char **argv)
 	std::string scene = "maincpp", mesh, sky_path, out = "output";
 	unsigned long long seed = 0x5EED;
 	bool whole_frame = false;
-	int device = 0;
+	int device = 0, gpus = 1, shards = 0;
 	for (int i = 1; i < argc; ++i)
 	{
 		std::string a = argv[i];
@@ -52,6 +53,8 @@ int main(int argc, char **argv)
 		else if (a == "--out") out = next();
 		else if (a == "--whole-frame") whole_frame = true;
 		else if (a == "--device") device = std::atoi(next());
+		else if (a == "--gpus") gpus = std::atoi(next());
+		else if (a == "--shards") shards = std::atoi(next());
 		else { usage(); return a == "--help" || a == "-h" ? 0 : 2; }
 	}
 	const int W = cfg.image_width, H = cfg.image_height();
@@ -124,6 +127,53 @@ int main(int argc, char **argv)
 	const size_t block_px = (size_t)blockSize.x * (size_t)blockSize.y;
 	std::vector<uint32_t> seeds(block_px);
 	wbrt_make_seeds(seed, 0, seeds.data(), seeds.size());
+
+	// Multi-GPU / sharded frame (no counterpart in the reference): the frame is `shards` seed shards of
+	// samples_per_pixel/shards samples each, GPU g renders the shards v % gpus == g, one all-reduce sums them.
+	if (shards > 0 || gpus > 1)
+	{
+		if (shards <= 0) shards = 8;
+		if (gpus <= 0) { std::fprintf(stderr, "--gpus must be positive\n"); return 2; }
+		std::vector<wbrt_context *> ctxs((size_t)gpus, nullptr);
+		std::vector<int32_t> devices((size_t)gpus);
+		ctxs[0] = ctx;
+		devices[0] = device;
+		for (int g = 1; g < gpus; ++g)
+		{
+			devices[(size_t)g] = device + g;
+			CHECK(wbrt_create(device + g, &ctxs[(size_t)g]));
+		}
+		std::printf("Writing to GPU memory (%d GPUs)...\n", gpus);
+		for (int g = 0; g < gpus; ++g)
+		{
+			CHECK(wbrt_upload_scene(ctxs[(size_t)g], spheres.data(), (int32_t)spheres.size(), triangles.data(), (int32_t)triangles.size(),
+			                        boxes.data(), (int32_t)boxes.size()));
+			CHECK(wbrt_upload_sky(ctxs[(size_t)g], sky.data(), skyw, skyh));
+		}
+		wbrt_comm *comm = nullptr;
+		CHECK(wbrt_comm_create(devices.data(), gpus, &comm));
+		std::vector<int32_t> shard_spp((size_t)shards);
+		wbrt_split_spp(cfg.samples_per_pixel, shards, shard_spp.data());
+		std::vector<float> sum((size_t)W * H * 3, 0.0f), image((size_t)W * H * 3);
+		std::vector<uint8_t> rgb8((size_t)W * H * 3, 0);
+		std::printf("Running kernel: %d seed shards of %d..%d spp over %d GPUs...\n", shards, shard_spp.back(), shard_spp.front(), gpus);
+		CHECK(wbrt_render_sharded_frame(comm, ctxs.data(), gpus, &camera, shards, shard_spp.data(), seed, sum.data())); // warm-up: schedules, RCCL channels
+		auto t0 = std::chrono::steady_clock::now();
+		CHECK(wbrt_render_sharded_frame(comm, ctxs.data(), gpus, &camera, shards, shard_spp.data(), seed, sum.data()));
+		const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+		std::printf(" === Done in %f s (%.1f Mpaths/s on %d GPUs incl. all-reduce and read-back) ===\n", secs,
+		            (double)W * H * cfg.samples_per_pixel / secs / 1e6, gpus);
+		const float total = (float)cfg.samples_per_pixel;
+		for (size_t i = 0; i < sum.size(); ++i) image[i] = sum[i] / total; // gpu_kernel.cl:647 over all shards
+		wbrt_tonemap_host(sum.data(), 1.0f / total, W, H, rgb8.data());
+		CHECK(wbrt_write_ppm((out + ".ppm").c_str(), rgb8.data(), W, H));
+		CHECK(wbrt_write_pfm((out + ".pfm").c_str(), image.data(), W, H));
+		CHECK(wbrt_write_exr((out + ".exr").c_str(), image.data(), W, H));
+		CHECK(wbrt_write_bmp((out + ".bmp").c_str(), rgb8.data(), W, H));
+		wbrt_comm_destroy(comm);
+		for (int g = 0; g < gpus; ++g) wbrt_destroy(ctxs[(size_t)g]);
+		return 0;
+	}
 
 	// uploads (main.cpp:160-205)
 	std::printf("Writing to GPU memory...\n");

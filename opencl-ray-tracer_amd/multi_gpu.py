@@ -12,11 +12,12 @@ and tone-maps (only rank 0 needs to keep the picture).
 torch is used for device memory, streams and the collective only; rendering goes through
 the C ABI (Context).
 """
-from . import OUT_ACCUMULATE, OUT_SUM, make_seeds
+from . import OUT_SUM
 
 
 def shards_for_rank(num_shards, rank, world):
-    return [v for v in range(num_shards) if v % world == rank]
+    from . import shards_of_rank
+    return shards_of_rank(num_shards, rank, world)
 
 
 class FrameBuffers:
@@ -48,30 +49,21 @@ def render_step(ctx, cam, frame, total_spp, stream=None, all_reduce=None):
 
 def split_spp(total_spp, num_shards):
     """Samples per shard when total_spp is not a multiple of the shard count: the first
-    total_spp % num_shards shards take one sample more."""
-    q, r = divmod(total_spp, num_shards)
-    return [q + 1 if v < r else q for v in range(num_shards)]
+    total_spp % num_shards shards take one sample more (wbrt_split_spp)."""
+    from . import split_spp as _split
+    return _split(total_spp, num_shards)
 
 
 def render_sharded_frame(ctx, cam, frame, num_shards, base_seed, rank, world, stream=None, all_reduce=None,
                          shard_spp=None):
     """Strong-scaling form: a frame of num_shards seed shards split over `world` ranks.  Every
     shard holds cam.samplesPerPixel samples, or shard_spp[v] when a list is given (see
-    split_spp).  Returns the number of shards this rank rendered."""
-    bw, bh = int(cam.blockSize.x), int(cam.blockSize.y)
-    frame.accum.zero_()
-    mine = shards_for_rank(num_shards, rank, world)
+    split_spp).  The shard loop is the C ABI's (wbrt_render_shards: seeds generated on the device,
+    no host synchronisation between shards).  Returns the number of shards this rank rendered."""
     total = num_shards * cam.samplesPerPixel if shard_spp is None else sum(shard_spp)
-    for v in mine:
-        c = cam
-        if shard_spp is not None:
-            c = cam.copy()
-            c.samplesPerPixel = int(shard_spp[v])
-        ctx.synchronize()  # the previous launch must be done before its seed buffer is replaced
-        ctx.upload_seeds(make_seeds(bw * bh, base_seed, shard=v))
-        ctx.render_frame_device(c, frame.accum.data_ptr(), OUT_ACCUMULATE, stream)
+    ctx.render_shards(cam, frame.accum.data_ptr(), num_shards, base_seed, rank, world, shard_spp, stream)
     if all_reduce is not None:
         all_reduce(frame.accum)
     ctx.tonemap_device(frame.accum.data_ptr(), 1.0 / float(total), cam.width, cam.height,
                        frame.rgb8.data_ptr(), stream)
-    return len(mine)
+    return len(shards_for_rank(num_shards, rank, world))

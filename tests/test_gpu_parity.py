@@ -310,6 +310,27 @@ def test_output_modes_and_shard_sum(gpu_ctx):
     assert np.array_equal(bits(acc), bits((sums[0] + sums[1]) + sums[2]))
 
 
+def test_device_seeds_equal_host_seeds(gpu_ctx):
+    """wbrt_make_seeds_device writes the seeds of wbrt_make_seeds: a render from them equals a render from the uploaded
+    host buffer, for several shards and a seed count that is not a multiple of the launch block."""
+    scene, cam = pkg.scene_readme(), pkg.camera_readme(200, 3, 50)
+    bw, bh = pkg.set_blocks(cam, 1)
+    gpu_ctx.upload_scene(scene)
+    for shard in (0, 1, 7, 4000000000):
+        gpu_ctx.upload_seeds(pkg.make_seeds(bw * bh, 0xABCDEF0123, shard=shard))
+        want = gpu_ctx.render_frame(cam)
+        gpu_ctx.upload_seeds(np.zeros(bw * bh, dtype=np.uint32))
+        gpu_ctx.make_seeds_device(bw * bh, 0xABCDEF0123, shard)
+        assert np.array_equal(bits(gpu_ctx.render_frame(cam)), bits(want))
+    # growing the buffer on the device path
+    big = pkg.camera_readme(328, 2, 50)
+    bw2, bh2 = pkg.set_blocks(big, 1)
+    gpu_ctx.make_seeds_device(bw2 * bh2, 5, 2)
+    got = gpu_ctx.render_frame(big)
+    gpu_ctx.upload_seeds(pkg.make_seeds(bw2 * bh2, 5, shard=2))
+    assert np.array_equal(bits(got), bits(gpu_ctx.render_frame(big)))
+
+
 @pytest.mark.parametrize("name", ["readme", "stress"])
 def test_schedule_reuse_never_changes_a_result(gpu_ctx, name):
     """Launches scheduled from a pilot, from the previous launch's recorded costs (same and other seeds,

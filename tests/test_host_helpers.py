@@ -5,6 +5,8 @@ import os
 import re
 import struct
 
+import pytest
+
 import numpy as np
 
 from util import pkg, ROOT, golden
@@ -276,3 +278,24 @@ def test_setters_reject_a_null_context():
     for name in ("wbrt_set_schedule_reuse", "wbrt_set_mesh_mode", "wbrt_set_timing"):
         assert getattr(lib, name)(None, 1) < 0
         assert lib.wbrt_last_error()
+
+
+def test_shard_helpers_through_the_c_abi():
+    """Shard assignment and sample split of the C ABI (wbrt_shards_of_rank, wbrt_split_spp): every shard has exactly
+    one owner, ranks differ by at most one shard, the samples add up."""
+    for V in (1, 2, 5, 8, 13):
+        for K in (1, 2, 4, 8):
+            parts = [pkg.shards_of_rank(V, r, K) for r in range(K)]
+            assert sorted(sum(parts, [])) == list(range(V))
+            assert all(v % K == r for r, p in enumerate(parts) for v in p)
+            assert max(map(len, parts)) - min(map(len, parts)) <= 1
+    assert pkg.split_spp(250, 8) == [32, 32, 31, 31, 31, 31, 31, 31]
+    assert pkg.split_spp(1000, 8) == [125] * 8
+    assert pkg.split_spp(3, 8) == [1, 1, 1, 0, 0, 0, 0, 0]
+    with pytest.raises(ValueError):
+        pkg.shards_of_rank(4, 2, 2)
+    # a communicator over one GPU needs neither RCCL nor a device buffer exchange; without any GPU it fails cleanly
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(pkg.WbrtError):
+            pkg.Comm([0])

@@ -42,6 +42,20 @@ class OracleContext:
         else:
             dst[:] = s / np.float32(cam.samplesPerPixel)
 
+    def render_shards(self, cam, ptr, num_shards, base_seed=0x5EED, rank=0, world=1, shard_spp=None, stream=None):
+        """wbrt_render_shards: zero, then += the clamped sum of every shard of this rank (host seeds stand in for the
+        device generator, which test_gpu_parity checks against them)."""
+        n = cam.width * cam.height * 3
+        dst = np.ctypeslib.as_array((C.c_float * n).from_address(ptr))
+        dst[:] = 0
+        bw, bh = int(cam.blockSize.x), int(cam.blockSize.y)
+        for v in pkg.shards_of_rank(num_shards, rank, world):
+            c = cam.copy()
+            if shard_spp is not None:
+                c.samplesPerPixel = int(shard_spp[v])
+            self.upload_seeds(pkg.make_seeds(bw * bh, base_seed, shard=v))
+            self.render_frame_device(c, ptr, pkg.OUT_ACCUMULATE)
+
     def tonemap_device(self, ptr, scale, width, height, out_ptr, stream=None):
         n = width * height * 3
         src = np.ctypeslib.as_array((C.c_float * n).from_address(ptr)).reshape(height, width, 3)
