@@ -7,9 +7,14 @@ pixel, depth 50, 4 blocks (the reference's default tiling), on N MI355X.
 
 One step = one frame: path-trace every pixel-sample on the GPU (inputs already resident in
 HBM), sum the un-normalised accumulation buffers over ranks (RCCL all-reduce, N > 1 only),
-normalise + gamma to 8-bit on the device.  With N ranks each rank renders its own
-250-spp seed shard of the same frame (weak scaling: the frame then holds 250*N samples per
-pixel), so value = N * 1280*720*250 paths / step time.
+normalise + gamma to 8-bit on the device.
+
+  N = 1   the frame is ONE launch with the reference's semantics (one random stream per pixel, 250 samples);
+          every step is a COLD frame: its launch schedule comes from its own pilot launch, nothing is carried
+          over from the previous step (config.ms_per_step_schedule_carried_over reports the other case);
+  N > 1   strong scaling on the SAME frame: 250 samples per pixel as 8 seed shards of 32/31 samples, shard v
+          rendered by rank v % N, one all-reduce(sum) of the 11 MB accumulation buffer per frame
+          (--weak: every rank renders its own 250-spp shard instead, the frame then holds 250*N samples).
 
 The JSON line also carries
   roofline      FP32-VALU roofline of the render kernel: algorithmic FLOPs of one launch
@@ -33,34 +38,56 @@ import __graft_entry__ as entry  # noqa: E402
 PEAK_FP32_VALU_TFLOPS = 157.3
 WIDTH, SPP, DEPTH, BLOCKS = 1280, 250, 50, 4
 BASE_SEED = 0x5EED
+SHARDS = 8
+CPU_SECONDS = 10.0
 
 
-def cpu_baseline(pkg, scene, cam, seeds):
-    """Times the CPU checker on whole blocks of the same workload until ~10 s have been spent."""
+def cpu_baseline(pkg, scene, cam, seeds, whole_blocks):
+    """Times the CPU checker on a bounded sample of the same workload (about CPU_SECONDS of wall time on up to 16
+    threads): whole blocks of the frame where a block finishes in seconds, else 64x8-pixel strips spread over the
+    frame (mesh scenes: the reference tests every triangle of a hit box for every ray segment)."""
     orc = entry.load_oracle()
     threads = max(1, min(16, os.cpu_count() or 1))
-    bw, bh = int(cam.blockSize.x), int(cam.blockSize.y)
-    nbx, nby = cam.width // bw, cam.height // bh
     if orc.have_ref():
         runner, kind = orc.Reference(scene), "reference"
-        run = lambda c: runner.render_block(c, seeds, threads)
+        run = lambda c, s: runner.render_block(c, s, threads)
     else:
         runner, kind = orc.Oracle(scene), "port"
-        run = lambda c: runner.render_block(c, seeds, math_mode=orc.MATH_PORTABLE, threads=threads)
+        run = lambda c, s: runner.render_block(c, s, math_mode=orc.MATH_PORTABLE, threads=threads)
+    c = cam.copy()
+    if whole_blocks:
+        bw, bh = int(cam.blockSize.x), int(cam.blockSize.y)
+        what = "blocks"
+    else:
+        bw, bh = 64, 8
+        c.blockSize = pkg.vec3(bw, bh, 0)
+        what = "64x8-pixel strips spread over the frame"
+    nbx, nby = cam.width // bw, cam.height // bh
+    s = np.ascontiguousarray(seeds[: bw * bh])
+    order = np.random.RandomState(1).permutation(nbx * nby) if not whole_blocks else np.arange(nbx * nby)
     done, t0 = 0, time.perf_counter()
-    for b in range(nbx * nby):
-        c = cam.copy()
-        c.blockOffset = pkg.vec3(b % nbx, b // nbx, 0)
-        run(c)
+    for b in order:
+        c.blockOffset = pkg.vec3(int(b) % nbx, int(b) // nbx, 0)
+        run(c, s)
         done += 1
-        if time.perf_counter() - t0 > 10.0:
+        if time.perf_counter() - t0 > CPU_SECONDS:
             break
     dt = time.perf_counter() - t0
     paths = done * bw * bh * cam.samplesPerPixel
     return {
-        "value": round(paths / dt / 1e6, 3), "unit": "Mpaths/s", "cores": threads, "kind": kind,
-        "sample": "%d of %d blocks (%dx%d px, %d spp) of the same frame, %.1f s" % (done, nbx * nby, bw, bh, cam.samplesPerPixel, dt),
+        "value": round(paths / dt / 1e6, 4), "unit": "Mpaths/s", "cores": threads, "kind": kind,
+        "sample": "%d of %d %s (%dx%d px, %d spp) of the same frame, %.1f s" % (done, nbx * nby, what, bw, bh, cam.samplesPerPixel, dt),
     }
+
+
+def profiled_traffic(config):
+    """HBM bytes per launch of the render kernel from the committed PMC summary of this configuration
+    (profiles/r2/traffic.json, condensed from rocprofv3 --pmc passes), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r2", "traffic.json")) as f:
+            return json.load(f).get(config)
+    except (OSError, ValueError):
+        return None
 
 
 def main():
@@ -69,16 +96,18 @@ def main():
     ap.add_argument("--steps", type=int, default=None, help="default 20 (readme, mesh), 3 (uhd), 2 (stress)")
     ap.add_argument("--warmup", type=int, default=None, help="default 3 (readme, mesh), 1 (uhd, stress)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-pilot-comparison", action="store_true",
-                    help="skip the untimed extra frames that price a pilot launch before every frame (profiling runs)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the untimed extra measurements after the timed region (profiling runs)")
+    ap.add_argument("--weak", action="store_true",
+                    help="readme/mesh with N > 1: every rank renders its own full-spp shard (weak scaling) instead of the split frame")
     ap.add_argument("--frames-in-flight", type=int, default=1,
                     help="throughput mode: steps alternate over this many contexts/streams so that the tail of one frame "
                          "overlaps the start of the next (default 1: one frame at a time, ms_per_step is a frame time)")
     ap.add_argument("--config", choices=["readme", "mesh", "uhd", "stress"], default="readme",
                     help="readme = headline (BASELINE.json configs[1]); mesh = configs[2]: main.cpp spheres + f1_car mesh, "
                          "1920x1080, 100 spp; uhd = configs[3]: README scene 3840x2160, 1000 spp as 8 seed shards of 125 spp "
-                         "split over the ranks (strong scaling); stress = configs[4]: 500 random spheres + 100352-triangle "
-                         "mesh in 256 bounding boxes, 3840x2160, 500 spp as 8 seed shards of 63/62 spp (strong scaling)")
+                         "split over the ranks; stress = configs[4]: 500 random spheres + 100352-triangle "
+                         "mesh in 256 bounding boxes, 3840x2160, 500 spp as 8 seed shards of 63/62 spp")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = {"uhd": 3, "stress": 2}.get(args.config, 20)
@@ -108,41 +137,50 @@ def main():
 
     pkg = entry.load_package()
     mg = __import__("importlib").import_module(entry.PKG_NAME + ".multi_gpu")
-    spp = SPP
-    sharded = args.config in ("uhd", "stress")
-    shard_spp = None
     if args.config == "mesh":
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from util import scene_main_cpp_with_mesh  # builds the scene from the committed triangle soup
-        scene = scene_main_cpp_with_mesh("f1_car")
-        spp = 100
-        cam = pkg.camera_main_cpp(1920, spp, DEPTH)
-        workload = ("main.cpp scene: 8 spheres + f1_car mesh (15329 triangles, 1 bounding box), 1920x1080, 100 spp per GPU shard, "
-                    "depth 50, 4 blocks of 960x540 (BASELINE.json configs[2])")
+        soup = np.load(os.path.join(ROOT, "tests", "golden", "meshes.npz"))["f1_car"]  # parsed vertex soup of the reference's f1_car.obj (data)
+        scene = pkg.scene_main_cpp_from_soup(soup)
+        total_spp = 100
+        cam = pkg.camera_main_cpp(1920, total_spp, DEPTH)
+        name = "main.cpp scene: 8 spheres + f1_car mesh (15329 triangles, 1 bounding box), 1920x1080, 100 spp, depth 50, 4 blocks of 960x540 (BASELINE.json configs[2])"
+        always_sharded = False
     elif args.config == "uhd":
         scene = pkg.scene_readme()
-        shards, spp = 8, 125
-        if shards % world:
-            raise SystemExit("--config uhd splits 8 seed shards: use 1, 2, 4 or 8 GPUs")
-        cam = pkg.camera_readme(3840, spp, DEPTH)
-        workload = ("README 5-sphere scene, 3840x2160, 1000 spp = 8 seed shards x 125 spp split over the ranks, depth 50, "
-                    "4 blocks of 1920x1080 (BASELINE.json configs[3]); seed buffers (8.3 MB per shard) are uploaded inside the step")
+        total_spp = 1000
+        cam = pkg.camera_readme(3840, total_spp, DEPTH)
+        name = "README 5-sphere scene, 3840x2160, 1000 spp, depth 50, 4 blocks of 1920x1080 (BASELINE.json configs[3])"
+        always_sharded = True
     elif args.config == "stress":
         scene = pkg.scene_stress(500, 224, 224, 16, 16)
-        shards, spp = 8, 500
-        if shards % world:
-            raise SystemExit("--config stress splits 8 seed shards: use 1, 2, 4 or 8 GPUs")
-        shard_spp = mg.split_spp(spp, shards)
-        cam = pkg.camera_stress(3840, max(shard_spp), DEPTH)
-        workload = ("divergence stress: 500 random Lambertian/metal spheres + 100352-triangle mesh in 256 bounding boxes, 3840x2160, "
-                    "500 spp = 8 seed shards of 63/62 spp split over the ranks, depth 50, 4 blocks of 1920x1080 (BASELINE.json configs[4])")
+        total_spp = 500
+        cam = pkg.camera_stress(3840, total_spp, DEPTH)
+        name = ("divergence stress: 500 random Lambertian/metal spheres + 100352-triangle mesh in 256 bounding boxes, 3840x2160, "
+                "500 spp, depth 50, 4 blocks of 1920x1080 (BASELINE.json configs[4])")
+        always_sharded = True
     else:
         scene = pkg.scene_readme()
-        cam = pkg.camera_readme(WIDTH, SPP, DEPTH)
-        workload = ("README 5-sphere scene, 1280x720, 250 spp per GPU shard, depth 50, 4 blocks of 640x360, "
-                    "bit-matched 48-bit LCG streams (BASELINE.json configs[1])")
+        total_spp = SPP
+        cam = pkg.camera_readme(WIDTH, total_spp, DEPTH)
+        name = "README 5-sphere scene, 1280x720, 250 spp, depth 50, 4 blocks of 640x360, bit-matched 48-bit LCG streams (BASELINE.json configs[1])"
+        always_sharded = False
     bw, bh = pkg.set_blocks(cam, BLOCKS)
-    seeds = pkg.make_seeds(bw * bh, BASE_SEED, shard=rank)  # rank r renders seed shard r
+    # how the frame is cut
+    weak = args.weak and world > 1 and not always_sharded
+    sharded = always_sharded or (world > 1 and not weak)
+    if sharded:
+        if SHARDS % world:
+            raise SystemExit("the frame is %d seed shards: use 1, 2, 4 or 8 GPUs" % SHARDS)
+        shard_spp = pkg.split_spp(total_spp, SHARDS)
+        cam.samplesPerPixel = max(shard_spp)
+        workload = name + "; frame = %d seed shards of %d/%d spp, shard v on rank v %% %d" % (SHARDS, max(shard_spp), min(shard_spp), world)
+        paths_per_step = cam.width * cam.height * total_spp
+        scaling = "strong"
+    else:
+        shard_spp = None
+        workload = name + ("; one launch with the reference's semantics" if world == 1 else "; WEAK scaling: one %d-spp seed shard per rank" % total_spp)
+        paths_per_step = cam.width * cam.height * total_spp * world
+        scaling = "weak"
+    seeds = pkg.make_seeds(bw * bh, BASE_SEED, shard=rank)  # single-launch steps: rank r renders seed shard r
 
     nfl = max(1, args.frames_in_flight)
     if nfl > 1 and sharded:
@@ -159,6 +197,7 @@ def main():
         streams.append(torch.cuda.current_stream() if nfl == 1 else torch.cuda.Stream(priority=-(k % 2)))
     ctx, frame, stream = ctxs[0], frames[0], streams[0].cuda_stream
     step_no = [0]
+    cold = [True]  # every step schedules itself (pilot launch); False: costs carried over from the previous step
 
     def all_reduce(t, op=None):
         op = op or dist.ReduceOp.SUM
@@ -171,16 +210,18 @@ def main():
 
     def step():
         if sharded:
-            mg.render_sharded_frame(ctx, cam, frame, shards, BASE_SEED, rank, world, stream=stream,
+            if cold[0]:
+                ctx.set_schedule_reuse(True)  # forgets the recorded costs: the frame's first shard runs a pilot, its other shards reuse it
+            mg.render_sharded_frame(ctx, cam, frame, SHARDS, BASE_SEED, rank, world, stream=stream,
                                     all_reduce=all_reduce if world > 1 else None, shard_spp=shard_spp)
         elif nfl == 1:
-            mg.render_step(ctx, cam, frame, total_spp=spp * world, stream=stream,
+            mg.render_step(ctx, cam, frame, total_spp=total_spp * world, stream=stream,
                            all_reduce=all_reduce if world > 1 else None)
         else:
             k = step_no[0] % nfl
             step_no[0] += 1
             with torch.cuda.stream(streams[k]):
-                mg.render_step(ctxs[k], cam, frames[k], total_spp=spp * world, stream=streams[k].cuda_stream,
+                mg.render_step(ctxs[k], cam, frames[k], total_spp=total_spp * world, stream=streams[k].cuda_stream,
                                all_reduce=all_reduce if world > 1 else None)
 
     def barrier():
@@ -188,17 +229,24 @@ def main():
         if world > 1:
             dist.barrier()
 
+    def timed(n):
+        barrier()
+        t = time.perf_counter()
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        return time.perf_counter() - t
+
+    if not sharded:
+        for c in ctxs:
+            c.set_schedule_reuse(False)  # cold frames: a pilot launch before every frame
     for _ in range(args.warmup):
         step()
     barrier()
     if nfl == 1:
         ctx.set_timing(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
+    dt = timed(args.steps)
     kernel_ms, launches = ctx.get_timing()
     ctx.set_timing(False)
     if world > 1:
@@ -206,114 +254,125 @@ def main():
         all_reduce(t, dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # the same step with every launch scheduled from its own pilot launch (no costs carried over from the
-    # previous frame), for comparison: what a frame of a new view costs
-    pilot_ms = None
-    if nfl == 1 and not sharded and not args.no_pilot_comparison:
-        ctx.set_schedule_reuse(False)
+    extras = {}
+    if nfl == 1 and not args.no_extras:
+        # the same step with the launch schedule carried over from the previous (identical) frame: no pilot launch
+        cold[0] = False
+        if not sharded:
+            ctx.set_schedule_reuse(True)
         step()
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(5):
-            step()
-        barrier()
-        pilot_ms = (time.perf_counter() - t1) / 5 * 1e3
-        ctx.set_schedule_reuse(True)
+        ctx.set_timing(True)
+        reps = 1 if always_sharded else 5
+        carried = timed(reps) / reps * 1e3
+        k_ms, k_n = ctx.get_timing()
+        ctx.set_timing(False)
+        extras["ms_per_step_schedule_carried_over"] = round(carried, 4)
+        extras["kernel_ms_per_launch_schedule_carried_over"] = round(k_ms / max(k_n, 1), 4)
+        cold[0] = True
+        if not sharded:
+            ctx.set_schedule_reuse(False)
+        if world == 1 and not sharded and args.config in ("readme", "mesh"):
+            # the N > 1 form of this workload on one GPU: the same frame as 8 seed shards (baseline of the scaling curve)
+            sspp = pkg.split_spp(total_spp, SHARDS)
+            c8 = cam.copy()
+            c8.samplesPerPixel = max(sspp)
 
-    # mesh configuration: the same step in the opt-in capped-margin walk (not proven equal to the reference's
-    # triangle loop; the timed steps above ran the default, proven mode), for comparison
-    capped_ms = None
-    if args.config == "mesh" and nfl == 1:
-        ctx.set_mesh_mode(pkg.MESH_BVH_CAPPED)
-        step()
-        step()
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(3):
+            def step8():
+                ctx.set_schedule_reuse(True)
+                mg.render_sharded_frame(ctx, c8, frame, SHARDS, BASE_SEED, 0, 1, stream=stream, shard_spp=sspp)
+            step8()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                step8()
+            barrier()
+            extras["ms_per_step_as_8_seed_shards_on_1_gpu"] = round((time.perf_counter() - t1) / 5 * 1e3, 4)
+            ctx.set_schedule_reuse(False)
+            ctx.upload_seeds(seeds)
+        if args.config == "mesh" and not sharded:
+            # the opt-in capped-margin walk (NOT proven equal to the reference's triangle loop; the timed steps ran the
+            # default, proven mode), for comparison
+            ctx.set_mesh_mode(pkg.MESH_BVH_CAPPED)
             step()
-        barrier()
-        capped_ms = (time.perf_counter() - t1) / 3 * 1e3
-        ctx.set_mesh_mode(pkg.MESH_BVH)
+            step()
+            extras["ms_per_step_in_WBRT_MESH_BVH_CAPPED"] = round(timed(3) / 3 * 1e3, 3)
+            ctx.set_mesh_mode(pkg.MESH_BVH)
 
-    if args.config == "uhd":
-        paths_per_step = cam.width * cam.height * spp * shards
-    elif args.config == "stress":
-        paths_per_step = cam.width * cam.height * spp
-    else:
-        paths_per_step = cam.width * cam.height * spp * world
-    result = None
     if rank == 0:
-        launch_paths = cam.width * cam.height * cam.samplesPerPixel
-        if args.config == "stress":
-            # the counting build runs the reference's sequential loops (every triangle of every hit box): counted on a
-            # 480x270 x 2 spp rendering of the same scene and scaled per path to one shard launch
-            small = pkg.camera_stress(480, 2, DEPTH)
+        launch_spp = cam.samplesPerPixel if not sharded else total_spp / SHARDS
+        launch_paths = cam.width * cam.height * launch_spp
+        hw_note = None
+        if args.config in ("mesh", "stress"):
+            # Hardware roofline of a mesh scene: the reference's algorithm tests every triangle of a hit box, the walk skips
+            # almost all of them, so counted FLOPs / walk time is not a hardware rate.  The fraction is therefore measured
+            # where the kernel executes exactly the counted work: WBRT_MESH_LOOP, at a reduced frame.
+            small = pkg.camera_main_cpp(1920, 4, DEPTH) if args.config == "mesh" else pkg.camera_stress(960, 2, DEPTH)
             sbw, sbh = pkg.set_blocks(small, BLOCKS)
             ctx.upload_seeds(pkg.make_seeds(sbw * sbh, BASE_SEED))
             counters = ctx.count_events(small)
-            launch_paths = cam.width * cam.height * (spp / shards)
-            flops = pkg.algorithmic_flops(counters) / (small.width * small.height * small.samplesPerPixel) * launch_paths
+            small_flops = pkg.algorithmic_flops(counters)
+            small_paths = small.width * small.height * small.samplesPerPixel
+            small_buf = torch.zeros(small.width * small.height * 3, dtype=torch.float32, device="cuda")
+            ctx.set_mesh_mode(pkg.MESH_LOOP)
+            ctx.set_schedule_reuse(False)
+            ctx.render_frame_device(small, small_buf.data_ptr(), pkg.OUT_SUM, stream)
+            torch.cuda.synchronize()
+            ctx.set_timing(True)
+            ctx.render_frame_device(small, small_buf.data_ptr(), pkg.OUT_SUM, stream)
+            torch.cuda.synchronize()
+            loop_ms, loop_n = ctx.get_timing()
+            ctx.set_timing(False)
+            ctx.set_mesh_mode(pkg.MESH_BVH)
+            flops = small_flops / small_paths * launch_paths  # reference-equivalent FLOPs of one launch of the timed workload
+            achieved = small_flops / (loop_ms * 1e-3) / 1e12
+            hw_note = ("measured in WBRT_MESH_LOOP (the kernel then executes the reference's own triangle loop, i.e. exactly the counted "
+                       "FLOPs) on %dx%d x %d spp of the same scene: %.3e FLOP in %.2f ms; the timed workload itself walks a hierarchy "
+                       "and skips most of that work" % (small.width, small.height, small.samplesPerPixel, small_flops, loop_ms))
+            ctx.upload_seeds(seeds)
         else:
-            counters = ctx.count_events(cam)  # exact event counts of this rank's launch (untimed)
-            flops = pkg.algorithmic_flops(counters)
-        if nfl > 1:  # overlapping launches have no meaningful individual duration: price the frame rate instead
-            kernel_ms, launches = dt * 1e3, args.steps
+            count_cam = cam.copy()
+            count_cam.samplesPerPixel = max(1, int(round(launch_spp)))
+            counters = ctx.count_events(count_cam)  # exact event counts of one launch (untimed)
+            flops = pkg.algorithmic_flops(counters) * (launch_spp / count_cam.samplesPerPixel)
+            if nfl > 1:  # overlapping launches have no meaningful individual duration: price the frame rate instead
+                kernel_ms, launches = dt * 1e3, args.steps
+            achieved = flops / (kernel_ms / max(launches, 1) * 1e-3) / 1e12
         k_ms = kernel_ms / max(launches, 1)
-        achieved = flops / (k_ms * 1e-3) / 1e12
+        traffic = profiled_traffic(args.config)
         result = {
             "metric": "Mpaths/s", "value": round(paths_per_step * args.steps / dt / 1e6, 2), "unit": "Mpaths/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if sharded else "weak",
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": workload,
-                "paths_per_step": paths_per_step, "parallelism": "spp-shard x%d + all-reduce(sum) of the %.2f MB accumulation buffer" % (world, cam.width * cam.height * 12 / 1e6),
-                "kernel_ms_per_launch": round(k_ms, 4), "frames_in_flight": nfl,
-                "schedule": "waves launched costliest first; costs recorded by the previous launch of the same view "
-                            "(a launch without one runs a 4-spp pilot launch first)",
-                "ms_per_step_with_pilot_every_frame": None if pilot_ms is None else round(pilot_ms, 4),
-                "readme_published_gpu_frame_s": 0.38,
+                "paths_per_step": paths_per_step,
+                "parallelism": ("1 GPU" if world == 1 else
+                                "%d ranks, spp split as seed shards + one all-reduce(sum) of the %.2f MB accumulation buffer per frame" % (
+                                    world, cam.width * cam.height * 12 / 1e6)),
+                "kernel_ms_per_launch": round(k_ms, 4), "render_launches_per_step": round(launches / max(args.steps, 1), 2), "frames_in_flight": nfl,
+                "schedule": "waves launched costliest first; every timed step prices its pixel streams with its own 4-spp pilot launch "
+                            "(cold frame, nothing carried over from the previous step)" + ("; the shards of one frame share that schedule" if sharded else ""),
+                "kernel_ms_per_launch_includes": "pilot launch + cost sort + render launch (HIP events on the launch stream)",
             },
             "roofline": {
                 "bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4),
-                # HBM bytes of a full launch from rocprofv3 PMC passes (profiles/r1/final_headline_summary.txt, largest
-                # dispatch): WRITE_SIZE 14.4 MB + 2 x FETCH_SIZE 3.67 MB (gfx950 tallies wide reads at half; an upper
-                # bound here); algorithmic bytes are 11.06 MB image + 3.69 MB recorded costs + 0.92 MB seeds + 0.06 MB schedule
-                "traffic": 21.8e6 if args.config == "readme" else None, "traffic_unit": "bytes/launch (PMC, profiled run)",
+                "traffic": None if traffic is None else traffic.get("bytes_per_launch"),
+                "traffic_source": None if traffic is None else traffic.get("source"),
                 "flops_per_launch": flops, "flop_per_path": round(flops / launch_paths, 2),
-                "note": "peak is the packed-FMA FP32 vector rate; results are bit-exact with a non-contracting IEEE build, so "
-                        "counted FLOPs issue as separate mul/add (measured ceiling 0.87 G wave-inst/s/SIMD = 57 TFLOP/s)",
+                "note": hw_note or ("peak = 256 CUs x 4 SIMDs x 32 lanes x 2 FLOP (FMA) x 2.4 GHz; results are bit-exact with a non-contracting "
+                                    "IEEE build, so a counted FLOP issues as a separate mul or add: ceiling 0.5 of peak before divergence"),
             },
         }
-        if capped_ms is not None:
-            result["config"]["mesh_mode"] = "WBRT_MESH_BVH (default: hierarchy walk with proven margins, same result as the reference's triangle loop)"
-            result["config"]["ms_per_step_in_WBRT_MESH_BVH_CAPPED"] = round(capped_ms, 3)
+        result["config"].update(extras)
+        if args.config == "readme":
+            result["config"]["readme_published_gpu_frame_s"] = 0.38
         if args.config in ("mesh", "stress"):
-            result["config"].pop("readme_published_gpu_frame_s", None)
-            # the FLOP count prices every triangle test the reference's loop performs; the hierarchy walk
-            # skips almost all of them, so this is a reference-equivalent work rate, not a hardware fraction
-            result["roofline"]["frac"] = None
-            if args.config == "mesh":
-                # profiles/r1/final_mesh_bvh_summary.txt, largest dispatch: WRITE_SIZE 33.7 MB (image 24.9 MB + recorded costs
-                # 8.3 MB) + 2 x FETCH_SIZE 11.6 MB; the mesh (0.7 MB of triangles, 0.3 MB of nodes) stays in L2
-                result["roofline"]["traffic"] = 56.9e6
-                result["roofline"]["hbm_gb_per_s"] = round(56.9e6 / (k_ms * 1e-3) / 1e9, 2)
-            if args.config == "stress":
-                # profiles/r1/final_stress_summary.txt, largest dispatch (one 63-spp shard): WRITE_SIZE 133.7 MB (accumulation
-                # read-modify-write 99.5 MB + recorded costs 33 MB) + 2 x FETCH_SIZE 73.4 GB: the 100352 triangles and their
-                # hierarchies (7 MB) exceed an XCD's 4 MB L2, so node and triangle fetches go to the fabric
-                result["roofline"]["traffic"] = 146.9e9
-                result["roofline"]["hbm_gb_per_s"] = round(146.9e9 / (k_ms * 1e-3) / 1e9, 1)
-            result["roofline"]["note"] = ("reference-equivalent rate: FLOPs are those of the reference's per-box triangle loop "
-                                          "(every triangle of a hit box tested); the kernel walks a hierarchy instead and executes far fewer")
-        if sharded:
-            result["config"].pop("readme_published_gpu_frame_s", None)
-            result["config"]["parallelism"] = "8 seed shards / %d ranks + all-reduce(sum) of the %.1f MB accumulation buffer" % (
-                world, cam.width * cam.height * 12 / 1e6)
-            result["roofline"]["traffic"] = None
-        if world == 1 and not args.no_cpu_baseline and args.config == "readme":
-            result["cpu_baseline"] = cpu_baseline(pkg, scene, cam, seeds)
+            result["config"]["mesh_mode"] = "WBRT_MESH_BVH (default: hierarchy walk with proven margins, same result as the reference's triangle loop)"
+            result["config"]["reference_equivalent_tflops"] = round(flops / (k_ms * 1e-3) / 1e12, 2)
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(pkg, scene, cam.copy(), seeds, whole_blocks=args.config in ("readme", "uhd"))
         print(json.dumps(result), flush=True)
     for c in ctxs:
         c.close()

@@ -347,6 +347,42 @@ def scene_main_cpp(mesh_path=None):
     return Scene(spheres=s, triangles=tris, boxes=boxes)
 
 
+def triangles_from_soup(soup, scale, translate, mat, box_id=0):
+    """Triangle array + bounding box from a raw [T,9] float32 vertex soup, with the reference loader's
+    arithmetic: vertex = v*scale + translate in float (utility.cpp:115-119) and the box
+    maximum initialised to FLT_MIN (main.cpp:114-115)."""
+    s = np.asarray(scale, dtype=np.float32)
+    t = np.asarray(translate, dtype=np.float32)
+    v = np.asarray(soup).reshape(-1, 3, 3).astype(np.float32)
+    w = ((v * s[None, None, :]).astype(np.float32) + t[None, None, :]).astype(np.float32)
+    n = w.shape[0]
+    tris = (Triangle * n)()
+    arr = np.frombuffer(tris, dtype=np.float32).reshape(n, 16)
+    arr[:, :9] = w.reshape(n, 9)
+    arr[:, 9] = mat.albedo.x
+    arr[:, 10] = mat.albedo.y
+    arr[:, 11] = mat.albedo.z
+    arr[:, 12] = mat.fuzz
+    arr[:, 13] = mat.ior
+    arr.view(np.int32)[:, 14] = mat.type
+    arr.view(np.int32)[:, 15] = box_id
+    flat = w.reshape(-1, 3)
+    mn = np.minimum(flat.min(axis=0), np.float32(np.finfo(np.float32).max))
+    mx = np.maximum(flat.max(axis=0), np.float32(np.finfo(np.float32).tiny))
+    return tris, mn, mx
+
+
+def scene_main_cpp_from_soup(soup):
+    """main.cpp:98-129 scene (eight spheres + one mesh in one bounding box) from an already parsed vertex soup
+    ([T,9] float32, untransformed OBJ coordinates) instead of an OBJ file."""
+    base = scene_main_cpp()
+    tris, mn, mx = triangles_from_soup(soup, (0.15, 0.15, 0.15), (0.0, -0.5, -1.0),
+                                       material((0.8, 0.6, 0.2), 0.5, 0.0, METAL), 0)
+    boxes = (BoundingBox * 1)()
+    boxes[0] = BoundingBox(0, vec3(*mn), vec3(*mx))
+    return Scene(spheres=base.spheres, triangles=tris, boxes=boxes)
+
+
 def scene_stress(n_spheres=500, nx=224, nz=224, boxes_x=16, boxes_z=16, base_seed=2024):
     """Divergence-stress scene: random Lambertian/metal spheres + a height-field mesh in many boxes."""
     s = (Sphere * n_spheres)()

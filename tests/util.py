@@ -24,41 +24,12 @@ def golden_meta(z):
     return json.loads(bytes(z["meta"]).decode())
 
 
-def triangles_from_soup(soup, scale, translate, mat, box_id=0):
-    """Triangle array + bounding box from a raw [T,9] float32 soup, with the reference loader's
-    arithmetic: vertex = v*scale + translate in float (utility.cpp:115-119) and the box
-    maximum initialised to FLT_MIN (main.cpp:114-115)."""
-    s = np.asarray(scale, dtype=np.float32)
-    t = np.asarray(translate, dtype=np.float32)
-    v = soup.reshape(-1, 3, 3).astype(np.float32)
-    w = (v * s[None, None, :]).astype(np.float32) + t[None, None, :]
-    w = w.astype(np.float32)
-    n = w.shape[0]
-    tris = (pkg.Triangle * n)()
-    arr = np.frombuffer(tris, dtype=np.float32).reshape(n, 16)
-    arr[:, :9] = w.reshape(n, 9)
-    arr[:, 9] = mat.albedo.x
-    arr[:, 10] = mat.albedo.y
-    arr[:, 11] = mat.albedo.z
-    arr[:, 12] = mat.fuzz
-    arr[:, 13] = mat.ior
-    arr.view(np.int32)[:, 14] = mat.type
-    arr.view(np.int32)[:, 15] = box_id
-    flat = w.reshape(-1, 3)
-    mn = np.minimum(flat.min(axis=0), np.float32(np.finfo(np.float32).max))
-    mx = np.maximum(flat.max(axis=0), np.float32(np.finfo(np.float32).tiny))
-    return tris, mn, mx
+triangles_from_soup = pkg.triangles_from_soup
 
 
 def scene_main_cpp_with_mesh(mesh="f1_car"):
     """main.cpp:98-129 scene built from the committed triangle soup (no OBJ file needed)."""
-    soup = golden("meshes.npz")[mesh]
-    base = pkg.scene_main_cpp()
-    tris, mn, mx = triangles_from_soup(soup, (0.15, 0.15, 0.15), (0.0, -0.5, -1.0),
-                                       pkg.material((0.8, 0.6, 0.2), 0.5, 0.0, pkg.METAL), 0)
-    boxes = (pkg.BoundingBox * 1)()
-    boxes[0] = pkg.BoundingBox(0, pkg.vec3(*mn), pkg.vec3(*mx))
-    return pkg.Scene(spheres=base.spheres, triangles=tris, boxes=boxes)
+    return pkg.scene_main_cpp_from_soup(golden("meshes.npz")[mesh])
 
 
 def scene_by_tag(tag):
