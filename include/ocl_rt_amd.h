@@ -210,6 +210,24 @@ int wbrt_render_sharded_frame(wbrt_comm *comm, wbrt_context *const *ctxs, int32_
 enum { WBRT_MESH_LOOP = 0, WBRT_MESH_BVH = 1, WBRT_MESH_BVH_CAPPED = 2 };
 int wbrt_set_mesh_mode(wbrt_context *ctx, int mode);
 
+/* Arithmetic of the render launches (wbrt_render_block / _frame / _frame_device / _shards).  No counterpart in the
+ * reference, whose OpenCL build passes no options (main.cpp:45) and so leaves contraction and the precision of / and sqrt
+ * to the device.
+ *   WBRT_ARITH_STRICT    (default) IEEE binary32 without contraction, correctly rounded / and sqrt, the reference's
+ *                        evaluation order (gpu_kernel.cl:108-257,455-555): images bit-identical to a non-contracting
+ *                        host build of the reference kernel;
+ *   WBRT_ARITH_TOLERANT  the same algorithm and the same random streams with fused multiply-adds, the hardware's 1-ulp
+ *                        reciprocal / square root and no error-margin bookkeeping: faster; a sample's path can differ
+ *                        from the reference's where a decision falls within rounding distance, so images agree within
+ *                        a tolerance, not bit for bit.  Measured: README scene against the reference kernel, 320x180 x
+ *                        250 spp: mean absolute error 2e-4, PSNR 59 dB (bar: 1e-3 / 40 dB); main.cpp scenes with and
+ *                        without the mesh below 1e-3; scenes with dozens of small spheres, where paths bounce
+ *                        chaotically, 1.4e-3 / 49 dB against the strict image (any change of arithmetic, a contracting
+ *                        OpenCL build of the reference included, moves a fixed share of such paths).
+ * wbrt_primary_ids_frame and wbrt_count_events_frame are always strict.  Takes effect at the next render. */
+enum { WBRT_ARITH_STRICT = 0, WBRT_ARITH_TOLERANT = 1 };
+int wbrt_set_arith_mode(wbrt_context *ctx, int mode);
+
 /* Launch schedule.  Waves are launched costliest pixel streams first.  The costs come from the
  * previous render launch of the same view (camera vectors, aperture, image and block size, block
  * offset, depth, scene, mesh mode): every launch records the ray segments each pixel stream took.

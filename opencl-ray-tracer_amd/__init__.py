@@ -89,6 +89,7 @@ def build(force=False):
 
 _lib = None
 MESH_LOOP, MESH_BVH, MESH_BVH_CAPPED = 0, 1, 2
+ARITH_STRICT, ARITH_TOLERANT = 0, 1
 
 # name -> (restype, argtypes); every symbol declared in include/ocl_rt_amd.h
 _P = C.c_void_p
@@ -118,6 +119,7 @@ _SIGNATURES = {
     "wbrt_render_sharded_frame": (C.c_int, [_P, _P, C.c_int32, C.POINTER(Camera), C.c_int32, _P, C.c_uint64, _P]),
     "wbrt_set_mesh_mode": (C.c_int, [_P, C.c_int]),
     "wbrt_set_schedule_reuse": (C.c_int, [_P, C.c_int]),
+    "wbrt_set_arith_mode": (C.c_int, [_P, C.c_int]),
     "wbrt_set_timing": (C.c_int, [_P, C.c_int]),
     "wbrt_get_timing": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_int]),
     "wbrt_device_info": (C.c_int, [_P, C.c_char_p, C.c_size_t]),
@@ -494,6 +496,10 @@ class Context:
     def set_mesh_mode(self, mode):
         """MESH_LOOP, MESH_BVH (default, proven equal to the loop) or MESH_BVH_CAPPED; see include/ocl_rt_amd.h."""
         _check(lib().wbrt_set_mesh_mode(self._h, int(mode)))
+
+    def set_arith_mode(self, mode):
+        """ARITH_STRICT (default, bit-exact) or ARITH_TOLERANT (fused/approximate arithmetic); see include/ocl_rt_amd.h."""
+        _check(lib().wbrt_set_arith_mode(self._h, int(mode)))
 
     def set_schedule_reuse(self, on=True):
         """Schedule a launch from the costs its predecessor recorded (default) or always from a pilot launch."""

@@ -165,6 +165,7 @@ int make_params(wbrt_context *ctx, const wbrt_camera *cam, bool whole_frame, Ren
 		p.out_w = bsx;
 	}
 	p.seeds = (const uint32_t *)ctx->seeds.p;
+	p.tolerant = ctx->arith_mode == WBRT_ARITH_TOLERANT ? 1 : 0;
 	p.sc = ctx->sc;
 	// strict margins on a small mesh widen every box to the whole mesh: the cooperative loop is faster there
 	const bool strict_small = ctx->mesh_mode == WBRT_MESH_BVH && ctx->sc.T <= ctx->strict_loop_max && !ctx->have_sphere_tree;
@@ -785,6 +786,14 @@ int wbrt_set_mesh_mode(wbrt_context *ctx, int mode)
 	if (!ctx) return fail(WBRT_ERR_INVALID, "null context");
 	if (mode < WBRT_MESH_LOOP || mode > WBRT_MESH_BVH_CAPPED) return fail(WBRT_ERR_INVALID, "bad mesh mode");
 	ctx->mesh_mode = mode;
+	return WBRT_OK;
+}
+
+int wbrt_set_arith_mode(wbrt_context *ctx, int mode)
+{
+	if (!ctx) return fail(WBRT_ERR_INVALID, "null context");
+	if (mode != WBRT_ARITH_STRICT && mode != WBRT_ARITH_TOLERANT) return fail(WBRT_ERR_INVALID, "bad arithmetic mode");
+	ctx->arith_mode = mode;
 	return WBRT_OK;
 }
 

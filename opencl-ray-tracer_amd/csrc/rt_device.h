@@ -82,6 +82,7 @@ struct RenderParams
 	                                // (indexed by work index, whatever the launch order)
 	const int *order;               // optional: waves (groups of 64 work indices) sorted by estimated cost, descending
 	const uint32_t *seeds;
+	int tolerant;                   // 1: the tolerant arithmetic build of the render kernel (render launches only)
 	SceneDev sc;
 };
 

@@ -277,6 +277,43 @@ def test_many_spheres_walk_equals_loop_and_oracle(gpu_ctx, case):
     assert np.array_equal(gpu_ctx.primary_ids(cam), O.primary_ids(cam, seeds))
 
 
+def test_tolerant_arithmetic_mode_within_image_tolerance(gpu_ctx):
+    """WBRT_ARITH_TOLERANT (fused multiply-adds, hardware reciprocal / square root, no margin bookkeeping) against the
+    reference kernel's own 320x180 x 250 spp image: primary ids bit-exact, image MAE <= 1e-3 and PSNR >= 40 dB (the
+    tolerance BASELINE.json states); the strict mode meets the same bar and is bit-exact against the oracle."""
+    z = golden("img_readme_320x180_s250_b4.npz")
+    meta = golden_meta(z)
+    scene, cam = scene_by_tag("readme"), camera_by_meta(meta)
+    seeds = _setup(gpu_ctx, scene, cam, meta["blocks"], meta["seed"])
+    try:
+        gpu_ctx.set_arith_mode(pkg.ARITH_TOLERANT)
+        tol = gpu_ctx.render_frame(cam)
+        assert np.array_equal(gpu_ctx.primary_ids(cam), z["ids"])
+        gpu_ctx.set_arith_mode(pkg.ARITH_STRICT)
+        strict = gpu_ctx.render_frame(cam)
+        mae, psnr = image_error(tol, z["image"])
+        assert mae <= 1e-3 and psnr >= 40.0, (mae, psnr)
+        mae_s, psnr_s = image_error(strict, z["image"])
+        assert mae_s <= 1e-3 and psnr_s >= 40.0, (mae_s, psnr_s)
+        assert not np.array_equal(bits(tol), bits(strict))  # it really is another arithmetic
+        assert np.array_equal(bits(strict), bits(orc.Oracle(scene).render_frame(cam, seeds, threads=16)))
+        # other scenes against their strict image.  Scenes with many small spheres are chaotic (a path that bounces between
+        # them amplifies a last-bit difference by an order of magnitude per bounce), so a fixed share of their samples ends
+        # elsewhere under ANY change of arithmetic, a contracting OpenCL build of the reference included: looser bound there.
+        for sc, c, bound in ((pkg.scene_main_cpp(), pkg.camera_main_cpp(320, 128, 50), 1e-3),
+                             (scene_main_cpp_with_mesh("f1_car"), pkg.camera_main_cpp(320, 64, 50), 1e-3),
+                             (pkg.scene_stress(60, 48, 48, 6, 6), pkg.camera_stress(192, 250, 50), 3e-3)):
+            _setup(gpu_ctx, sc, c, 4, 34)
+            gpu_ctx.set_arith_mode(pkg.ARITH_STRICT)
+            a = gpu_ctx.render_frame(c)
+            gpu_ctx.set_arith_mode(pkg.ARITH_TOLERANT)
+            b = gpu_ctx.render_frame(c)
+            mae, psnr = image_error(b, a)
+            assert mae <= bound and psnr >= 40.0, (sc.S, sc.T, mae, psnr)
+    finally:
+        gpu_ctx.set_arith_mode(pkg.ARITH_STRICT)
+
+
 def test_block_entry_point_equals_frame_region(gpu_ctx):
     scene, cam = pkg.scene_readme(), pkg.camera_readme(160, 4, 50)
     _setup(gpu_ctx, scene, cam, 4, 12)
