@@ -40,3 +40,16 @@ for d in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write", "pmc_tcp"):
         print("  kernel %s" % k[:70])
         for c, vals in sorted(ctrs.items()):
             print("    %-28s %18.1f  (n=%d, max %.1f)" % (c, sum(vals) / len(vals), len(vals), max(vals)))
+
+# HBM bytes of one full render launch for bench.py's roofline.traffic: WRITE_SIZE + 2 x FETCH_SIZE of the largest
+# dispatch (both counters are in KB; gfx950 tallies wide reads at half their bytes, so the doubled figure is an upper bound)
+if len(sys.argv) > 2:
+    import json
+    fetch = max((max(v["FETCH_SIZE"]) for k, v in pmc("pmc_fetch").items() if "k_render<false" in k), default=None)
+    write = max((max(v["WRITE_SIZE"]) for k, v in pmc("pmc_write").items() if "k_render<false" in k), default=None)
+    if fetch is not None and write is not None:
+        entry = {"bytes_per_launch": (write + 2.0 * fetch) * 1024.0, "fetch_kb": fetch, "write_kb": write,
+                 "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, largest k_render<false,...> dispatch: WRITE_SIZE + 2 x FETCH_SIZE (profiles/r2, %s)" % os.path.basename(out)}
+        path = os.path.join(out, "traffic_%s.json" % sys.argv[2])
+        json.dump({sys.argv[2]: entry}, open(path, "w"), indent=1)
+        print("== wrote %s: %.1f MB per launch" % (path, entry["bytes_per_launch"] / 1e6))
