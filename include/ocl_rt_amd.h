@@ -55,7 +55,8 @@ typedef enum
 	WBRT_ERR_NO_DEVICE = -2,   /* no usable HIP device */
 	WBRT_ERR_HIP = -3,         /* a HIP runtime call failed (message has the hipError name) */
 	WBRT_ERR_OOM = -4,
-	WBRT_ERR_IO = -5
+	WBRT_ERR_IO = -5,
+	WBRT_ERR_CANCELLED = -6    /* a block callback asked to stop */
 } wbrt_status;
 
 /* what a render writes per pixel */
@@ -98,6 +99,13 @@ int wbrt_upload_seeds(wbrt_context *ctx, const uint32_t *seeds, size_t n);
  * enqueueNDRangeKernel + blocking enqueueReadBuffer (main.cpp:234-247).
  * out_block: blockSize.x*blockSize.y texels indexed by in-block id (row 0 = bottom). */
 int wbrt_render_block(wbrt_context *ctx, const wbrt_camera *camera, wbrt_vec3 *out_block);
+
+/* the reference's block loop with progressive delivery (main.cpp:229-267: after every block the picture is updated and
+ * the viewer polls it): blocks are rendered in its order (block rows from the top down, columns left to right) and handed
+ * to `callback` one by one (block: block_w*block_h texels, row 0 = bottom, valid during the call); a non-zero return
+ * stops the loop (WBRT_ERR_CANCELLED). */
+typedef int (*wbrt_block_callback)(void *user, int32_t block_x, int32_t block_y, int32_t block_w, int32_t block_h, const wbrt_vec3 *block);
+int wbrt_render_blocks(wbrt_context *ctx, const wbrt_camera *camera, wbrt_block_callback callback, void *user);
 
 /* replaces the whole block loop (main.cpp:229-260) with ONE launch over every block;
  * blockOffset in *camera is ignored, blockSize selects the tiling (and therefore the
@@ -282,6 +290,14 @@ int wbrt_write_bmp(const char *path, const uint8_t *rgb8, int32_t width, int32_t
 int wbrt_read_mesh(const char *path, wbrt_vec3 scale, wbrt_vec3 translate, wbrt_material material,
                    int32_t bounding_box_id, wbrt_triangle *triangles, int32_t *triangle_count,
                    int32_t *vertex_count, wbrt_vec3 *box_min, wbrt_vec3 *box_max);
+
+/* Order-preserving bounding-box splitter: the T triangles of ONE mesh (the reference loads a whole OBJ into one box,
+ * main.cpp:111-129) are cut into target_boxes contiguous runs of the array; run k gets boundingBoxId = first_box_id + k
+ * and boxes_out[k] = its bounds widened by pad x its largest extent (maxima starting at FLT_MIN like main.cpp:114-115
+ * when flt_min_quirk != 0).  The reference's loops then meet the triangles in the same order as with one box
+ * (gpu_kernel.cl:374-391), and a ray tests only the runs whose box it enters.  Returns the boxes written or -1. */
+int32_t wbrt_split_mesh_boxes(wbrt_triangle *triangles, int32_t triangle_count, int32_t first_box_id, int32_t target_boxes,
+                              float pad, int32_t flt_min_quirk, wbrt_bounding_box *boxes_out, int32_t max_boxes);
 
 /* sky tone map of ReadHdrImageData (utility.cpp:172-190): c' = 1 + 1/pow(-1-c, 5) */
 void wbrt_sky_tonemap(const float *rgb_in, size_t n_texels, wbrt_vec3 *out);

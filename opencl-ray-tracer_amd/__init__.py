@@ -101,6 +101,7 @@ _SIGNATURES = {
     "wbrt_upload_sky": (C.c_int, [_P, _P, C.c_int32, C.c_int32]),
     "wbrt_upload_seeds": (C.c_int, [_P, _P, C.c_size_t]),
     "wbrt_render_block": (C.c_int, [_P, C.POINTER(Camera), _P]),
+    "wbrt_render_blocks": (C.c_int, [_P, C.POINTER(Camera), _P, _P]),
     "wbrt_render_frame": (C.c_int, [_P, C.POINTER(Camera), C.c_int, _P]),
     "wbrt_render_frame_device": (C.c_int, [_P, C.POINTER(Camera), C.c_int, _P, _P]),
     "wbrt_render_frame_device_noalloc": (C.c_int, [_P, C.POINTER(Camera), C.c_int, _P, _P]),
@@ -135,6 +136,7 @@ _SIGNATURES = {
     "wbrt_write_exr": (C.c_int, [C.c_char_p, _P, C.c_int32, C.c_int32]),
     "wbrt_read_mesh": (C.c_int, [C.c_char_p, Vec3, Vec3, Material, C.c_int32, _P, C.POINTER(C.c_int32),
                                  C.POINTER(C.c_int32), C.POINTER(Vec3), C.POINTER(Vec3)]),
+    "wbrt_split_mesh_boxes": (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P, C.c_int32]),
     "wbrt_sky_tonemap": (None, [_P, C.c_size_t, _P]),
     "wbrt_load_hdr": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.POINTER(C.c_float))]),
     "wbrt_free": (None, [_P]),
@@ -287,6 +289,17 @@ def read_mesh(path, scale, translate, mat, bounding_box_id=0):
     _check(lib().wbrt_read_mesh(path.encode(), vec3(*scale), vec3(*translate), mat, bounding_box_id, tris,
                                 C.byref(cap), C.byref(nv), C.byref(mn), C.byref(mx)))
     return (Triangle * cap.value).from_buffer(tris) if cap.value else (Triangle * 0)(), mn, mx, nv.value
+
+
+def split_mesh_boxes(triangles, target_boxes, first_box_id=0, pad=1e-4, flt_min_quirk=False):
+    """Cuts one mesh (a ctypes Triangle array, modified in place: boundingBoxId) into contiguous runs with a bounding box
+    each (wbrt_split_mesh_boxes); returns the BoundingBox array."""
+    n = min(target_boxes, len(triangles))
+    boxes = (BoundingBox * max(n, 1))()
+    got = lib().wbrt_split_mesh_boxes(triangles, len(triangles), first_box_id, target_boxes, pad, 1 if flt_min_quirk else 0, boxes, n)
+    if got < 0:
+        raise ValueError("wbrt_split_mesh_boxes failed")
+    return (BoundingBox * got).from_buffer_copy(bytes(boxes)[: got * C.sizeof(BoundingBox)])
 
 
 def sky_tonemap(rgb):
@@ -445,6 +458,16 @@ class Context:
         out = np.empty((bh, bw, 3), dtype=np.float32)
         _check(lib().wbrt_render_block(self._h, C.byref(cam), _ptr(out)))
         return out
+
+    def render_blocks(self, cam, on_block):
+        """wbrt_render_blocks: on_block(bx, by, block[h, w, 3]) per block in the reference's order; a true return stops."""
+        proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p)
+
+        def trampoline(_user, bx, by, w, h, ptr):
+            blk = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=(h, w, 3)).copy()
+            return 1 if on_block(bx, by, blk) else 0
+        cb = proto(trampoline)
+        _check(lib().wbrt_render_blocks(self._h, C.byref(cam), C.cast(cb, C.c_void_p), None))
 
     def render_frame(self, cam, out_mode=OUT_MEAN, into=None):
         out = into if into is not None else np.zeros((cam.height, cam.width, 3), dtype=np.float32)

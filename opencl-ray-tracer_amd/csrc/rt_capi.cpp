@@ -629,6 +629,28 @@ int wbrt_render_block(wbrt_context *ctx, const wbrt_camera *camera, wbrt_vec3 *o
 	return WBRT_OK;
 }
 
+int wbrt_render_blocks(wbrt_context *ctx, const wbrt_camera *camera, wbrt_block_callback callback, void *user)
+{
+	int rc = bind(ctx);
+	if (rc) return rc;
+	if (!camera || !callback) return fail(WBRT_ERR_INVALID, "null argument");
+	const int bsx = (int)camera->blockSize.x, bsy = (int)camera->blockSize.y;
+	if (bsx <= 0 || bsy <= 0 || camera->width <= 0 || camera->height <= 0 || camera->width % bsx || camera->height % bsy)
+		return fail(WBRT_ERR_INVALID, "blockSize must divide the image (main.cpp:222-223)");
+	std::vector<wbrt_vec3> block((size_t)bsx * bsy);
+	wbrt_camera c = *camera;
+	// main.cpp:229-231: block rows from the top of the picture down, columns left to right
+	for (int y = camera->height / bsy - 1; y >= 0; --y)
+		for (int x = 0; x < camera->width / bsx; ++x)
+		{
+			c.blockOffset.x = (float)x; c.blockOffset.y = (float)y; c.blockOffset.z = 0.0f;
+			rc = wbrt_render_block(ctx, &c, block.data());
+			if (rc) return rc;
+			if (callback(user, x, y, bsx, bsy, block.data()) != 0) return fail(WBRT_ERR_CANCELLED, "cancelled by the block callback");
+		}
+	return WBRT_OK;
+}
+
 int wbrt_render_frame_device(wbrt_context *ctx, const wbrt_camera *camera, int out_mode, void *device_image, void *stream)
 {
 	int rc = bind(ctx);

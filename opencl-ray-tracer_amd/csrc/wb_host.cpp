@@ -406,6 +406,44 @@ int wbrt_read_mesh(const char *path, wbrt_vec3 scale, wbrt_vec3 translate, wbrt_
 	return WBRT_OK;
 }
 
+// Splits one mesh into many bounding boxes (the reference puts a whole OBJ into ONE box, main.cpp:111-129, and then tests
+// every triangle of that box for every ray that enters it, gpu_kernel.cl:374-391; its kernel accepts any number of boxes).
+// Order-preserving: box k takes a CONTIGUOUS run of the triangle array, so the order in which the reference's loops meet
+// the triangles (boxes ascending, triangles ascending inside a box) is the array order, exactly as with one box, and ties
+// go to the same triangle (first one tested wins, gpu_kernel.cl:520).  boundingBoxId becomes first_box_id + k.  Boxes are
+// the runs' bounds widened by `pad` times their largest extent (a hit the float test accepts a rounding error outside its
+// triangle must still find its box entered); with flt_min_quirk the maxima start at FLT_MIN like main.cpp:114-115.
+// Returns the number of boxes written, or -1.
+int32_t wbrt_split_mesh_boxes(wbrt_triangle *triangles, int32_t triangle_count, int32_t first_box_id, int32_t target_boxes,
+                              float pad, int32_t flt_min_quirk, wbrt_bounding_box *boxes_out, int32_t max_boxes)
+{
+	if (!triangles || triangle_count <= 0 || target_boxes <= 0 || !boxes_out || !(pad >= 0.0f)) return -1;
+	const int32_t n = std::min(target_boxes, triangle_count);
+	if (n > max_boxes) return -1;
+	for (int32_t k = 0; k < n; ++k)
+	{
+		const int32_t a = (int32_t)((int64_t)triangle_count * k / n), b = (int32_t)((int64_t)triangle_count * (k + 1) / n);
+		wbrt_vec3 mn = V(FLT_MAX, FLT_MAX, FLT_MAX);
+		wbrt_vec3 mx = flt_min_quirk ? V(FLT_MIN, FLT_MIN, FLT_MIN) : V(-FLT_MAX, -FLT_MAX, -FLT_MAX);
+		for (int32_t j = a; j < b; ++j)
+		{
+			triangles[j].boundingBoxId = first_box_id + k;
+			const wbrt_vec3 *p[3] = { &triangles[j].p0, &triangles[j].p1, &triangles[j].p2 };
+			for (const wbrt_vec3 *v : p)
+			{
+				mn.x = std::min(mn.x, v->x); mn.y = std::min(mn.y, v->y); mn.z = std::min(mn.z, v->z);
+				mx.x = std::max(mx.x, v->x); mx.y = std::max(mx.y, v->y); mx.z = std::max(mx.z, v->z);
+			}
+		}
+		const float extent = std::max(std::max(mx.x - mn.x, mx.y - mn.y), mx.z - mn.z);
+		const float m = pad * (extent > 0.0f && extent < FLT_MAX ? extent : 0.0f);
+		boxes_out[k].id = first_box_id + k;
+		boxes_out[k].min = V(mn.x - m, mn.y - m, mn.z - m);
+		boxes_out[k].max = V(mx.x + m, mx.y + m, mx.z + m);
+	}
+	return n;
+}
+
 // utility.cpp:172-190: exposure exponent 2*2+1 = 5, evaluated in double, stored as float.
 void wbrt_sky_tonemap(const float *rgb_in, size_t n_texels, wbrt_vec3 *out)
 {

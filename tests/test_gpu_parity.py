@@ -213,6 +213,28 @@ def test_mesh_modes_identical(gpu_ctx, name):
     assert np.array_equal(gpu_ctx.primary_ids(c), O.primary_ids(c, seeds))
 
 
+def test_split_boxes_scene_equals_one_box_scene(gpu_ctx):
+    """The f1_car mesh cut into 64 bounding boxes by wbrt_split_mesh_boxes renders the picture of the one-box scene
+    (the boxes are supersets of their runs and the loops keep their order) in every mesh mode, and faster in the loop."""
+    one = scene_main_cpp_with_mesh("f1_car")
+    cut = scene_main_cpp_with_mesh("f1_car")
+    boxes = pkg.split_mesh_boxes(cut.triangles, 64)
+    cut = pkg.Scene(spheres=one.spheres, triangles=cut.triangles, boxes=boxes)
+    cam = pkg.camera_main_cpp(256, 4, 50)
+    seeds = _setup(gpu_ctx, one, cam, 4, 23)
+    try:
+        gpu_ctx.set_mesh_mode(pkg.MESH_LOOP)
+        want = gpu_ctx.render_frame(cam)
+        want_ids = gpu_ctx.primary_ids(cam)
+        gpu_ctx.upload_scene(cut)
+        for mode in (pkg.MESH_LOOP, pkg.MESH_BVH, pkg.MESH_BVH_CAPPED):
+            gpu_ctx.set_mesh_mode(mode)
+            assert np.array_equal(bits(gpu_ctx.render_frame(cam)), bits(want)), mode
+        assert np.array_equal(gpu_ctx.primary_ids(cam), want_ids)
+    finally:
+        gpu_ctx.set_mesh_mode(pkg.MESH_BVH)
+
+
 def test_mesh_goldens_at_size(gpu_ctx):
     """BASELINE configs[2] (main.cpp spheres + f1_car mesh) against the reference kernel's own
     output at sizes its host build still finishes: 480x270 image + ids, 1920x1080 primary ids.
@@ -325,6 +347,23 @@ def test_block_entry_point_equals_frame_region(gpu_ctx):
             c.blockOffset = pkg.vec3(bx, by, 0)
             blk = gpu_ctx.render_block(c)
             assert np.array_equal(bits(blk), bits(frame[by * bh:(by + 1) * bh, bx * bw:(bx + 1) * bw]))
+
+
+def test_block_callback_delivers_the_reference_order(gpu_ctx):
+    scene, cam = pkg.scene_readme(), pkg.camera_readme(160, 4, 50)
+    _setup(gpu_ctx, scene, cam, 4, 12)
+    bw, bh = int(cam.blockSize.x), int(cam.blockSize.y)
+    frame = gpu_ctx.render_frame(cam)
+    seen = []
+
+    def on_block(bx, by, blk):
+        assert np.array_equal(bits(blk), bits(frame[by * bh:(by + 1) * bh, bx * bw:(bx + 1) * bw]))
+        seen.append((bx, by))
+    gpu_ctx.render_blocks(cam, on_block)
+    assert seen == [(0, 1), (1, 1), (0, 0), (1, 0)]  # main.cpp:229-231: top block row first, columns ascending
+    with pytest.raises(pkg.WbrtError) as e:
+        gpu_ctx.render_blocks(cam, lambda bx, by, blk: True)
+    assert e.value.code == -6
 
 
 def test_output_modes_and_shard_sum(gpu_ctx):

@@ -299,3 +299,36 @@ def test_shard_helpers_through_the_c_abi():
     if not torch.cuda.is_available():
         with pytest.raises(pkg.WbrtError):
             pkg.Comm([0])
+
+
+def test_box_splitter_preserves_order_and_the_picture():
+    """wbrt_split_mesh_boxes: contiguous runs, ids ascending with the array, every triangle inside its (padded) box; the
+    split scene gives the oracle (the reference's loops) the same image and primary ids as the one-box scene."""
+    from util import orc, scene_main_cpp_with_mesh, bits
+    one = scene_main_cpp_with_mesh("burger")
+    split = scene_main_cpp_with_mesh("burger")
+    boxes = pkg.split_mesh_boxes(split.triangles, 12, first_box_id=0, pad=1e-4)
+    assert len(boxes) == 12
+    ids = np.frombuffer(split.triangles, dtype=np.int32).reshape(-1, 16)[:, 15]
+    assert (np.diff(ids) >= 0).all() and ids[0] == 0 and ids[-1] == 11
+    counts = np.bincount(ids)
+    assert counts.max() - counts.min() <= 1
+    pts = np.frombuffer(split.triangles, dtype=np.float32).reshape(-1, 16)[:, :9].reshape(-1, 3, 3)
+    for k in range(12):
+        sel = pts[ids == k].reshape(-1, 3)
+        assert boxes[k].id == k
+        assert (sel.min(0) > np.array(boxes[k].min.tuple())).all() and (sel.max(0) < np.array(boxes[k].max.tuple())).all()
+    # geometry untouched
+    a = np.frombuffer(one.triangles, dtype=np.float32).reshape(-1, 16)[:, :15]
+    b = np.frombuffer(split.triangles, dtype=np.float32).reshape(-1, 16)[:, :15]
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    split_scene = pkg.Scene(spheres=one.spheres, triangles=split.triangles, boxes=boxes)
+    cam = pkg.camera_main_cpp(96, 3, 50)
+    bw, bh = pkg.set_blocks(cam, 4)
+    seeds = pkg.make_seeds(bw * bh, 19)
+    want, got = orc.Oracle(one), orc.Oracle(split_scene)
+    assert np.array_equal(bits(got.render_frame(cam, seeds)), bits(want.render_frame(cam, seeds)))
+    assert np.array_equal(got.primary_ids(cam, seeds), want.primary_ids(cam, seeds))
+    # the FLT_MIN quirk: maxima never below 1.17549435e-38
+    q = pkg.split_mesh_boxes(scene_main_cpp_with_mesh("burger").triangles, 3, flt_min_quirk=True)
+    assert all(b.max.y >= 1.17549435e-38 and b.max.z >= 1.17549435e-38 for b in q)
