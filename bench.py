@@ -296,6 +296,8 @@ def main():
             ctx.upload_seeds(seeds)
         if args.arith == "strict" and not sharded:
             # the same cold step in the tolerant arithmetic mode, and how far its image is from the strict one
+            step()
+            torch.cuda.synchronize()
             strict_img = frame.accum.clone()
             ctx.set_arith_mode(pkg.ARITH_TOLERANT)
             step()

@@ -228,7 +228,9 @@ int scheduled_launch(wbrt_context *ctx, const RenderParams &p, hipStream_t strea
 	if (timing) { int rc = timing_begin(ctx, stream); if (rc) return rc; }
 	RenderParams q = p;
 	const long long total = (long long)p.bsx * p.bsy * p.nbx * p.nby;
-	if (ctx->lpt && total >= 65536 && total % 64 == 0 && p.spp >= 8 * ctx->pilot_spp)
+	// a pilot takes at most an eighth of the launch's samples (short seed shards get a shorter pilot)
+	const int pilot_spp = std::max(1, std::min(ctx->pilot_spp, p.spp / 8));
+	if (ctx->lpt && total >= 65536 && total % 64 == 0 && p.spp >= 8)
 	{
 		WbrtSchedule s;
 		if (fixed) s = *fixed;
@@ -257,14 +259,14 @@ int scheduled_launch(wbrt_context *ctx, const RenderParams &p, hipStream_t strea
 		std::memcpy(key.dims, dims, sizeof dims);
 		key.scene_generation = ctx->scene_generation;
 		key.walks = p.sc.bvh_nodes != nullptr;
-		int cost_spp = ctx->pilot_spp;
+		int cost_spp = pilot_spp;
 		const bool reuse = ctx->reuse_costs && !fixed;
 		const bool recorded = reuse && ctx->recorded_spp > 0 && std::memcmp(&key, &ctx->recorded_view, sizeof key) == 0;
 		if (recorded) cost_spp = ctx->recorded_spp;
 		else
 		{
 			RenderParams pilot = p;
-			pilot.spp = ctx->pilot_spp;
+			pilot.spp = pilot_spp;
 			if (ctx->pilot_depth > 0 && ctx->pilot_depth < pilot.max_depth) pilot.max_depth = ctx->pilot_depth;
 			pilot.costs = s.costs;
 			pilot.out = nullptr;
