@@ -438,6 +438,33 @@ def test_schedule_reuse_never_changes_a_result(gpu_ctx, name):
     gpu_ctx.set_schedule_reuse(True)
 
 
+def test_launches_of_one_context_on_two_streams_are_ordered(gpu_ctx):
+    """A context's schedule arrays and seed buffer are shared by its launches: a launch on another stream waits for the
+    previous one (event recorded after every render launch), so alternating two streams gives the sequential images."""
+    import torch
+    scene, cam = pkg.scene_readme(), pkg.camera_readme(384, 32, 50)
+    bw, bh = pkg.set_blocks(cam, 4)
+    gpu_ctx.upload_scene(scene)
+    gpu_ctx.set_schedule_reuse(False)
+    try:
+        want = []
+        for v in range(4):
+            gpu_ctx.upload_seeds(pkg.make_seeds(bw * bh, 55, shard=v))
+            want.append(gpu_ctx.render_frame(cam, pkg.OUT_SUM))
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        bufs = [torch.zeros(cam.height * cam.width * 3, dtype=torch.float32, device="cuda:0") for _ in range(4)]
+        torch.cuda.synchronize()
+        for v in range(4):  # no host synchronisation between the launches
+            st = streams[v % 2].cuda_stream
+            gpu_ctx.make_seeds_device(bw * bh, 55, v, stream=st)
+            gpu_ctx.render_frame_device(cam, bufs[v].data_ptr(), pkg.OUT_SUM, stream=st)
+        torch.cuda.synchronize()
+        for v in range(4):
+            assert np.array_equal(bits(bufs[v].cpu().numpy().reshape(want[v].shape)), bits(want[v])), v
+    finally:
+        gpu_ctx.set_schedule_reuse(True)
+
+
 def test_tonemap_device_equals_host(gpu_ctx):
     import torch
     scene, cam = pkg.scene_readme(), pkg.camera_readme(160, 4, 50)
