@@ -8,12 +8,15 @@
 // One binary hierarchy of axis-aligned boxes per bounding box lets the kernel skip the rest.
 //
 // What "could accept" means is decided by the float arithmetic of gpu_kernel.cl:489-520, not
-// by geometry: with u = 2^-24 and |det| >= 1e-5 (the test's own parallel cutoff) a forward
-// error analysis of that code bounds the distance between an accepted hit and the triangle
-// by about 29u/1e-5 * (|o-p0| + |e|) * |d| * |e0||e1|.  Nodes therefore carry
-// E = max |e0||e1| of their triangles and the kernel widens each box per ray by
-// 0.35 * E * R * |d| (R bounds |o-p0| + |e|); when E*|d| is so large that the rounding of det
-// itself is comparable with the cutoff the node is always visited.
+// by geometry: with u = 2^-24 a forward error analysis of that code bounds the distance between
+// the ray point of an accepted hit and the triangle by 26.5u |o-p0| |d||e0||e1| / |det|, det being
+// the float determinant the test computed.  |det| is bounded from below (1) by the test's own
+// cutoff 1e-5 and (2) by |e0||e1| times a lower bound of |d . m|, m = (e0 x e1)/(|e0||e1|), over
+// the triangles of a node.  Nodes therefore carry E = max |e0||e1| and a box around the m vectors
+// of their triangles (m-box), and the kernel widens each box per ray by the smaller of the two
+// margins (see the kernel for the formula).  Two builders: plain binned surface-area trees for
+// the walk with capped margins, and MarginBuilder, which prices splits with those margins and
+// also splits by orientation, for the walk with proven margins.
 #include "rt_device.h"
 
 #include <algorithm>
