@@ -86,6 +86,7 @@ struct wbrt_context
 	int bvh_depth[2] = {0, 0};
 	int mesh_mode = WBRT_MESH_BVH;
 	int bvh_steal_min_idle = 8;
+	int wg_kernel = 0, wg_per_cu = 0; // opt-in: waves (4 or 8) of the workgroup render kernel for scenes without meshes, and its workgroups per CU
 	int strict_loop_max = 4096;   // proven-margin mode: meshes up to this many triangles use the cooperative loop
 	float bvh_rho = 2e-4f; // WBRT_MESH_BVH_CAPPED: box margin as a fraction of the ray's distance bound
 	DevBuf sky, seeds, image, ids, counters, rgb8, costs, tile_costs, order, hist;
@@ -168,6 +169,8 @@ int make_params(wbrt_context *ctx, const wbrt_camera *cam, bool whole_frame, Ren
 	}
 	p.seeds = (const uint32_t *)ctx->seeds.p;
 	p.tolerant = ctx->arith_mode == WBRT_ARITH_TOLERANT ? 1 : 0;
+	p.wg = ctx->wg_kernel;
+	p.wg_per_cu = ctx->wg_per_cu;
 	p.sc = ctx->sc;
 	// strict margins on a small mesh widen every box to the whole mesh: the cooperative loop is faster there
 	const bool strict_small = ctx->mesh_mode == WBRT_MESH_BVH && ctx->sc.T <= ctx->strict_loop_max && !ctx->have_sphere_tree;
@@ -228,6 +231,13 @@ int scheduled_launch(wbrt_context *ctx, const RenderParams &p, hipStream_t strea
 	if (timing) { int rc = timing_begin(ctx, stream); if (rc) return rc; }
 	RenderParams q = p;
 	const long long total = (long long)p.bsx * p.bsy * p.nbx * p.nby;
+	if (ctx->wg_kernel && !fixed)
+	{
+		// the work counter of the persistent workgroups follows the histogram of the cost sort (uses alternate on one stream)
+		int rc = ctx->hist.reserve(257 * sizeof(unsigned));
+		if (rc) return rc;
+		q.next = (unsigned *)ctx->hist.p + 256;
+	}
 	// a pilot takes at most an eighth of the launch's samples (short seed shards get a shorter pilot)
 	const int pilot_spp = std::max(1, std::min(ctx->pilot_spp, p.spp / 8));
 	if (ctx->lpt && total >= 65536 && total % 64 == 0 && p.spp >= 8)
@@ -239,7 +249,7 @@ int scheduled_launch(wbrt_context *ctx, const RenderParams &p, hipStream_t strea
 			int rc = ctx->costs.reserve((size_t)(total + total / 64 + 1) * sizeof(int));
 			if (!rc) rc = ctx->order.reserve((size_t)(total / 64 + 1) * sizeof(int));
 			if (!rc) rc = ctx->tile_costs.reserve((size_t)(total / 64 + 1) * sizeof(int));
-			if (!rc) rc = ctx->hist.reserve(256 * sizeof(unsigned));
+			if (!rc) rc = ctx->hist.reserve(257 * sizeof(unsigned));
 			if (rc) return rc;
 			s.costs = (int *)ctx->costs.p; s.order = (int *)ctx->order.p;
 			s.tile_costs = (int *)ctx->tile_costs.p; s.hist = (unsigned *)ctx->hist.p;
@@ -265,7 +275,7 @@ int scheduled_launch(wbrt_context *ctx, const RenderParams &p, hipStream_t strea
 		if (recorded) cost_spp = ctx->recorded_spp;
 		else
 		{
-			RenderParams pilot = p;
+			RenderParams pilot = q;
 			pilot.spp = pilot_spp;
 			if (ctx->pilot_depth > 0 && ctx->pilot_depth < pilot.max_depth) pilot.max_depth = ctx->pilot_depth;
 			pilot.costs = s.costs;
@@ -879,6 +889,8 @@ int wbrt_tune_(wbrt_context *ctx, const char *key, int value)
 	else if (k == "sphere_tree_min") ctx->sphere_tree_min = value;
 	else if (k == "bvh_min_idle") ctx->bvh_steal_min_idle = value;
 	else if (k == "strict_loop_max") ctx->strict_loop_max = value;
+	else if (k == "wg_kernel") ctx->wg_kernel = value;
+	else if (k == "wg_per_cu") ctx->wg_per_cu = value;
 	else return fail(WBRT_ERR_INVALID, "unknown tuning key " + k);
 	ctx->recorded_spp = 0;
 	return WBRT_OK;

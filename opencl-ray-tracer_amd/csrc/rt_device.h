@@ -83,6 +83,10 @@ struct RenderParams
 	const int *order;               // optional: waves (groups of 64 work indices) sorted by estimated cost, descending
 	const uint32_t *seeds;
 	int tolerant;                   // 1: the tolerant arithmetic build of the render kernel (render launches only)
+	int wg;                         // 4 or 8: scenes without meshes use the workgroup kernel (that many waves) that re-deals pixel streams
+	                                // between its waves; 0: the per-wave kernel
+	int wg_per_cu;                  // workgroups per compute unit of that kernel's launch (0: 6 of 4 waves, 3 of 8)
+	unsigned *next;                 // workgroup kernel: work counter in device memory (the launch zeroes it)
 	SceneDev sc;
 };
 

@@ -255,6 +255,35 @@ hipError_t wbrt_launch_render(const RenderParams &p, hipStream_t stream)
 {
 	const dim3 grid(grid_for(p, WBRT_RENDER_BLOCK)), block(WBRT_RENDER_BLOCK);
 	const bool box_tree = p.sc.top_nodes && p.sc.bvh_nodes, mesh = p.sc.B > 0 || (p.sc.sph_tree && p.sc.bvh_nodes);
+	if (p.wg && !mesh && p.spp > 0 && p.next)
+	{
+		// opt-in form (measured slower than k_render on the headline frame; kept selectable for that measurement):
+		// persistent workgroups of p.wg waves, as many as the device holds at once (or fewer, for a small launch)
+		int device = -1, cus = 0;
+		hipError_t e = hipGetDevice(&device);
+		if (e != hipSuccess) return e;
+		e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+		if (e != hipSuccess) return e;
+		const int nt = p.wg >= 8 ? 512 : 256;
+		const int per_cu = p.wg_per_cu > 0 ? p.wg_per_cu : (nt == 512 ? 3 : 6);
+		const long long slots = (long long)cus * per_cu;
+		const long long total = (long long)p.bsx * p.bsy * p.nbx * p.nby;
+		const long long groups = (total + nt - 1) / nt;
+		const dim3 wg_grid((unsigned)(groups < slots ? groups : slots)), wg_block(nt);
+		e = hipMemsetAsync(p.next, 0, sizeof(unsigned), stream);
+		if (e != hipSuccess) return e;
+		if (nt == 512)
+		{
+			if (p.tolerant) hipLaunchKernelGGL(tolerant_impl::k_render_wg<512>, wg_grid, wg_block, 0, stream, p);
+			else hipLaunchKernelGGL(strict_impl::k_render_wg<512>, wg_grid, wg_block, 0, stream, p);
+		}
+		else
+		{
+			if (p.tolerant) hipLaunchKernelGGL(tolerant_impl::k_render_wg<256>, wg_grid, wg_block, 0, stream, p);
+			else hipLaunchKernelGGL(strict_impl::k_render_wg<256>, wg_grid, wg_block, 0, stream, p);
+		}
+		return hipGetLastError();
+	}
 	if (p.tolerant)
 	{
 		if (box_tree) hipLaunchKernelGGL((tolerant_impl::k_render<false, true, true>), grid, block, 0, stream, p);

@@ -1,0 +1,10 @@
+#!/bin/bash
+set -u
+cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
+for wg in 0 1; do
+  O=gpurun_out/wgprof_$wg; mkdir -p $O
+  timeout -s KILL 120 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 scripts/wg_prof.py $wg > $O/stats.log 2>&1 || { echo stats failed; tail -5 $O/stats.log; exit 1; }
+  timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_INSTS_LDS --output-format csv -d $O/pmc -- python3 scripts/wg_prof.py $wg > $O/pmc.log 2>&1 || { echo pmc failed; tail -5 $O/pmc.log; exit 1; }
+  timeout -s KILL 120 rocprofv3 --pmc SQ_INST_CYCLES_VALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM_RD --output-format csv -d $O/pmc2 -- python3 scripts/wg_prof.py $wg > $O/pmc2.log 2>&1 || { echo pmc2 failed; tail -5 $O/pmc2.log; }
+done
+echo done

@@ -438,6 +438,36 @@ def test_schedule_reuse_never_changes_a_result(gpu_ctx, name):
     gpu_ctx.set_schedule_reuse(True)
 
 
+@pytest.mark.parametrize("waves", [4, 8])
+def test_workgroup_kernel_equals_per_wave_kernel(waves):
+    """The opt-in render kernel that re-deals pixel streams between the waves of a persistent workgroup (tune key
+    wg_kernel; measured slower, kept for the measurement) never changes a result: oracle's image on a ragged small frame,
+    the per-wave kernel's image on a scheduled frame, in every output mode and both arithmetic modes."""
+    scene = pkg.scene_readme()
+    small = pkg.camera_readme(160, 7, 6)
+    sbw, sbh = pkg.set_blocks(small, 3)
+    cam = pkg.camera_readme(384, 24, 50)
+    bw, bh = pkg.set_blocks(cam, 4)
+    with pkg.Context(0) as ctx:
+        ctx.upload_scene(scene)
+        seeds = pkg.make_seeds(sbw * sbh, 7)
+        ctx.upload_seeds(seeds)
+        ctx.tune("wg_kernel", waves)
+        want = orc.Oracle(scene).render_frame(small, seeds, math_mode=orc.MATH_PORTABLE, threads=8)
+        assert np.array_equal(bits(ctx.render_frame(small)), bits(want))
+        ctx.upload_seeds(pkg.make_seeds(bw * bh, 9))
+        for arith in (pkg.ARITH_STRICT, pkg.ARITH_TOLERANT):
+            ctx.set_arith_mode(arith)
+            for mode in (pkg.OUT_MEAN, pkg.OUT_SUM):
+                for reuse in (False, True):
+                    ctx.set_schedule_reuse(reuse)
+                    ctx.tune("wg_kernel", 0)
+                    ref = ctx.render_frame(cam, mode)
+                    ctx.tune("wg_kernel", waves)
+                    assert np.array_equal(bits(ctx.render_frame(cam, mode)), bits(ref)), (arith, mode, reuse)
+                    assert np.array_equal(bits(ctx.render_frame(cam, mode)), bits(ref)), (arith, mode, reuse, "recorded")
+
+
 def test_launches_of_one_context_on_two_streams_are_ordered(gpu_ctx):
     """A context's schedule arrays and seed buffer are shared by its launches: a launch on another stream waits for the
     previous one (event recorded after every render launch), so alternating two streams gives the sequential images."""
