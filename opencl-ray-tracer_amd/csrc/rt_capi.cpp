@@ -469,7 +469,16 @@ int wbrt_upload_scene(wbrt_context *ctx, const wbrt_sphere *spheres, int32_t S,
 		if (sphere_tree) wbrt_append_sphere_tree(geom.data(), radius.data(), S, bvh);
 		static_assert(sizeof(WbrtBvhNode) == 4 * sizeof(float4), "node layout");
 		std::vector<float4> bnodes(bvh.nodes.size() * 4), btris(bvh.tri_index.size() * 3), broots(bvh.roots.size() * 2);
-		if (!bvh.nodes.empty()) std::memcpy(bnodes.data(), bvh.nodes.data(), bvh.nodes.size() * sizeof(WbrtBvhNode));
+		for (size_t n = 0; n < bvh.nodes.size(); ++n) // children interleaved: the kernel handles them as packed pairs
+		{
+			const WbrtBvhNode &b = bvh.nodes[n];
+			float left, right;
+			std::memcpy(&left, &b.left, 4); std::memcpy(&right, &b.right, 4);
+			bnodes[4 * n + 0] = make_float4(b.lmin[0], b.rmin[0], b.lmin[1], b.rmin[1]);
+			bnodes[4 * n + 1] = make_float4(b.lmin[2], b.rmin[2], b.lmax[0], b.rmax[0]);
+			bnodes[4 * n + 2] = make_float4(b.lmax[1], b.rmax[1], b.lmax[2], b.rmax[2]);
+			bnodes[4 * n + 3] = make_float4(left, right, b.le, b.re);
+		}
 		for (size_t k = 0; k < bvh.tri_index.size(); ++k)
 		{
 			const size_t src = (size_t)bvh.tri_index[k];

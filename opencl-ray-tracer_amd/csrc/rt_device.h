@@ -43,7 +43,8 @@ struct SceneDev
 	const int2   *box_range;  // [B] first, last+1 into the grouped triangle arrays
 	int B;
 	// triangle hierarchies, one per bounding box (absent: bvh_nodes == nullptr)
-	const float4 *bvh_nodes;  // 4 per node: lmin.xyz lmax.x | lmax.yz rmin.xy | rmin.z rmax.xyz | left right E_left E_right
+	const float4 *bvh_nodes;  // 4 per node, children interleaved: lmin.x rmin.x lmin.y rmin.y | lmin.z rmin.z lmax.x rmax.x |
+	                          // lmax.y rmax.y lmax.z rmax.z | left right E_left E_right
 	const float4 *bvh_tris;   // 3 per leaf slot: tri_geom layout, fourth word of the last float4 = position in the grouped order
 	const float4 *bvh_roots;  // 2 per box: min.xyz ref | max.xyz E   (E < 0: box without triangles)
 	const uint4  *bvh_mbox;   // 1 per node (proven-margin trees only): bytes 0-2 of x|y|z|w = left lo, left hi, right lo, right hi of the
