@@ -80,7 +80,7 @@ struct wbrt_context
 	DevBuf top_nodes, top_box;    // hierarchy over the boxes (scenes with box_tree_min or more boxes)
 	int top_depth = 0;            // 0: no such hierarchy
 	int box_tree_min = 48;        // measured crossover between 36 and 64 boxes
-	DevBuf bvh_nodes[2], bvh_tris[2], bvh_roots[2]; // [0] plain surface-area trees (capped margins), [1] built for the proven margins
+	DevBuf bvh_nodes[2], bvh_tris[2], bvh_roots[2], bvh_pairs[2]; // [0] plain surface-area trees (capped margins), [1] built for the proven margins
 	DevBuf bvh_mbox;              // m-boxes of the nodes of variant [1]
 	const float4 *bvh_ptr[2][3] = {};
 	int bvh_depth[2] = {0, 0};
@@ -180,6 +180,7 @@ int make_params(wbrt_context *ctx, const wbrt_camera *cam, bool whole_frame, Ren
 		p.sc.bvh_nodes = ctx->bvh_ptr[variant][0];
 		p.sc.bvh_tris = ctx->bvh_ptr[variant][1];
 		p.sc.bvh_roots = ctx->bvh_ptr[variant][2];
+		p.sc.bvh_pairs = (const float4 *)ctx->bvh_pairs[variant].p;
 		p.sc.bvh_mbox = variant == 1 ? (const uint4 *)ctx->bvh_mbox.p : nullptr;
 		p.sc.bvh_box_slots = WBRT_BVH_STACK - ctx->bvh_depth[variant] + 1;
 		if (ctx->top_depth > 0)
@@ -349,7 +350,7 @@ int wbrt_destroy(wbrt_context *ctx)
 	DevBuf *all[] = { &ctx->sph_geom, &ctx->sph_radius, &ctx->sph_mat_a, &ctx->sph_mat_b, &ctx->tri_geom,
 	                  &ctx->tri_mat_a, &ctx->tri_mat_b, &ctx->tri_orig, &ctx->box_min, &ctx->box_max,
 	                  &ctx->box_range, &ctx->bvh_nodes[0], &ctx->bvh_tris[0], &ctx->bvh_roots[0],
-	                  &ctx->bvh_nodes[1], &ctx->bvh_tris[1], &ctx->bvh_roots[1], &ctx->bvh_mbox, &ctx->top_nodes, &ctx->top_box, &ctx->sky, &ctx->seeds, &ctx->image, &ctx->ids, &ctx->counters, &ctx->rgb8,
+	                  &ctx->bvh_nodes[1], &ctx->bvh_tris[1], &ctx->bvh_roots[1], &ctx->bvh_pairs[0], &ctx->bvh_pairs[1], &ctx->bvh_mbox, &ctx->top_nodes, &ctx->top_box, &ctx->sky, &ctx->seeds, &ctx->image, &ctx->ids, &ctx->counters, &ctx->rgb8,
 	                  &ctx->costs, &ctx->tile_costs, &ctx->order, &ctx->hist };
 	for (DevBuf *b : all) b->release();
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -468,6 +469,33 @@ int wbrt_upload_scene(wbrt_context *ctx, const wbrt_sphere *spheres, int32_t S,
 		const size_t tri_slots = bvh.tri_index.size();
 		if (sphere_tree) wbrt_append_sphere_tree(geom.data(), radius.data(), S, bvh);
 		static_assert(sizeof(WbrtBvhNode) == 4 * sizeof(float4), "node layout");
+		// Triangle leaves are stored as PAIRS (the kernel tests two triangles per round with packed arithmetic), 5 float4 each:
+		// p0.x p0.x' p0.y p0.y' | p0.z p0.z' e0.x e0.x' | e0.y e0.y' e0.z e0.z' | e1.x e1.x' e1.y e1.y' | e1.z e1.z' pos pos'
+		// (pos = position in the grouped order; pos' = -1: no second triangle, its numbers repeat the first).  A leaf
+		// reference then counts pair slots: ~ref = (first pair << 4) | (pairs - 1).  Sphere leaves keep their one-sphere slots.
+		std::vector<float4> bpairs;
+		auto as_float = [](int v) { float f; std::memcpy(&f, &v, 4); return f; };
+		auto leaf_as_pairs = [&](int ref) {
+			if (ref >= 0) return ref;
+			const int leaf = ~ref, first_slot = leaf >> 4, count = (leaf & 15) + 1;
+			if ((size_t)first_slot >= tri_slots) return ref; // a sphere leaf, or the reference of a box without triangles
+			const int base = (int)(bpairs.size() / 5), pairs = (count + 1) / 2;
+			for (int k = 0; k < pairs; ++k)
+			{
+				const int ia = bvh.tri_index[(size_t)first_slot + 2 * k];
+				const int ib = 2 * k + 1 < count ? bvh.tri_index[(size_t)first_slot + 2 * k + 1] : -1;
+				const float4 *A = &tgeom[3 * (size_t)ia], *Bt = &tgeom[3 * (size_t)(ib >= 0 ? ib : ia)];
+				bpairs.push_back(make_float4(A[0].x, Bt[0].x, A[0].y, Bt[0].y));
+				bpairs.push_back(make_float4(A[0].z, Bt[0].z, A[0].w, Bt[0].w));
+				bpairs.push_back(make_float4(A[1].x, Bt[1].x, A[1].y, Bt[1].y));
+				bpairs.push_back(make_float4(A[1].z, Bt[1].z, A[1].w, Bt[1].w));
+				bpairs.push_back(make_float4(A[2].x, Bt[2].x, as_float(ia), as_float(ib)));
+			}
+			return ~((base << 4) | (pairs - 1));
+		};
+		for (WbrtBvhNode &b : bvh.nodes) { b.left = leaf_as_pairs(b.left); b.right = leaf_as_pairs(b.right); }
+		for (WbrtBvhRoot &r : bvh.roots) if (!r.empty) r.ref = leaf_as_pairs(r.ref);
+		if (bpairs.empty()) bpairs.resize(5, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
 		std::vector<float4> bnodes(bvh.nodes.size() * 4), btris(bvh.tri_index.size() * 3), broots(bvh.roots.size() * 2);
 		for (size_t n = 0; n < bvh.nodes.size(); ++n) // children interleaved: the kernel handles them as packed pairs
 		{
@@ -501,7 +529,7 @@ int wbrt_upload_scene(wbrt_context *ctx, const wbrt_sphere *spheres, int32_t S,
 			broots[2 * b] = make_float4(r.mn[0], r.mn[1], r.mn[2], ref);
 			broots[2 * b + 1] = make_float4(r.mx[0], r.mx[1], r.mx[2], r.empty ? -1.0f : r.e);
 		}
-		UP(bvh_nodes[variant], bnodes); UP(bvh_tris[variant], btris); UP(bvh_roots[variant], broots);
+		UP(bvh_nodes[variant], bnodes); UP(bvh_tris[variant], btris); UP(bvh_roots[variant], broots); UP(bvh_pairs[variant], bpairs);
 		if (variant == 1)
 		{
 			// m-box components as bytes, rounded outwards: lower bounds down, upper bounds up (b -> b/127 - 1)
@@ -539,6 +567,7 @@ int wbrt_upload_scene(wbrt_context *ctx, const wbrt_sphere *spheres, int32_t S,
 	SceneDev &sc = ctx->sc;
 	sc.bvh_nodes = sc.bvh_tris = sc.bvh_roots = nullptr; // chosen per render (make_params)
 	sc.bvh_mbox = nullptr;
+	sc.bvh_pairs = nullptr;
 	sc.bvh_rho = 0.0f;
 	sc.sph_tree = 0;
 	sc.sph_geom = (const float4 *)ctx->sph_geom.p; sc.sph_radius = (const float *)ctx->sph_radius.p;

@@ -45,7 +45,10 @@ struct SceneDev
 	// triangle hierarchies, one per bounding box (absent: bvh_nodes == nullptr)
 	const float4 *bvh_nodes;  // 4 per node, children interleaved: lmin.x rmin.x lmin.y rmin.y | lmin.z rmin.z lmax.x rmax.x |
 	                          // lmax.y rmax.y lmax.z rmax.z | left right E_left E_right
-	const float4 *bvh_tris;   // 3 per leaf slot: tri_geom layout, fourth word of the last float4 = position in the grouped order
+	const float4 *bvh_tris;   // 3 per leaf slot of the sphere hierarchy: center.xyz r^2 | - | - index - -
+	const float4 *bvh_pairs;  // 5 per pair slot of a triangle leaf, two triangles interleaved:
+	                          // p0.x p0.x' p0.y p0.y' | p0.z p0.z' e0.x e0.x' | e0.y e0.y' e0.z e0.z' | e1.x e1.x' e1.y e1.y' | e1.z e1.z' pos pos'
+	                          // (pos: position in the grouped order as int bits; pos' = -1: no second triangle)
 	const float4 *bvh_roots;  // 2 per box: min.xyz ref | max.xyz E   (E < 0: box without triangles)
 	const uint4  *bvh_mbox;   // 1 per node (proven-margin trees only): bytes 0-2 of x|y|z|w = left lo, left hi, right lo, right hi of the
 	                          // children's m-boxes, m = (e0 x e1)/(|e0||e1|), byte b -> b/127 - 1
@@ -92,7 +95,8 @@ struct RenderParams
 };
 
 // Binary hierarchy over the triangles of every bounding box.  A child reference >= 0 names a
-// node; < 0 names a leaf: ~ref = (first leaf slot << 4) | (triangles - 1).
+// node; < 0 names a leaf: ~ref = (first leaf slot << 4) | (triangles - 1) as built; on the device a triangle leaf counts
+// pair slots instead (see SceneDev::bvh_pairs).
 #define WBRT_BVH_STACK 24
 struct WbrtBvhNode
 {
