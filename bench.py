@@ -360,7 +360,7 @@ def main():
                 kernel_ms, launches = dt * 1e3, args.steps
             achieved = flops / (kernel_ms / max(launches, 1) * 1e-3) / 1e12
         k_ms = kernel_ms / max(launches, 1)
-        traffic = profiled_traffic(args.config)
+        traffic = profiled_traffic(args.config + ("_tolerant" if args.arith == "tolerant" else ""))
         result = {
             "metric": "Mpaths/s", "value": round(paths_per_step * args.steps / dt / 1e6, 2), "unit": "Mpaths/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

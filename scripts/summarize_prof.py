@@ -25,9 +25,13 @@ def pmc(dirname):
 for f in find("stats/**/*kernel_trace.csv"):
     durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(f)) if "k_render<false" in r["Kernel_Name"]]
     if durs:
-        full = [d for d in durs if d > 0.5 * max(durs)]
-        print("== k_render<false,.> dispatches: %d, of which full launches %d: mean %.1f ns (min %d, max %d); others (pilot): %s" % (
-            len(durs), len(full), sum(full) / len(full), min(full), max(full), [d for d in durs if d <= 0.5 * max(durs)]))
+        # the timed launches are the largest group: those near the median of the upper half of all durations (below them
+        # the pilot launches, above them e.g. the loop-mode launches of a mesh configuration's hardware roofline)
+        upper = sorted(durs)[len(durs) // 2:]
+        mid = upper[len(upper) // 2]
+        full = [d for d in durs if 0.75 * mid <= d <= 1.33 * mid]
+        print("== k_render<false,.> dispatches: %d, of which timed full launches %d: mean %.1f ns (min %d, max %d); shorter (pilot): %s; longer: %s" % (
+            len(durs), len(full), sum(full) / len(full), min(full), max(full), [d for d in durs if d < 0.75 * mid], [d for d in durs if d > 1.33 * mid]))
 
 for d in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write", "pmc_tcp"):
     acc = pmc(d)
