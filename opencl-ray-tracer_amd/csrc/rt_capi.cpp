@@ -4,10 +4,12 @@
 #include "../../include/ocl_rt_amd.h"
 #include "rt_device.h"
 
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <utility>
 #include <vector>
@@ -75,7 +77,7 @@ struct wbrt_context
 	int device = 0;
 	hipStream_t stream = nullptr; // used by the blocking entry points
 	DevBuf sph_geom, sph_radius, sph_mat_a, sph_mat_b;
-	DevBuf tri_geom, tri_mat_a, tri_mat_b, tri_orig;
+	DevBuf tri_geom, tri_shade, mat_table, tri_orig;
 	DevBuf box_min, box_max, box_range;
 	DevBuf top_nodes, top_box;    // hierarchy over the boxes (scenes with box_tree_min or more boxes)
 	int top_depth = 0;            // 0: no such hierarchy
@@ -348,7 +350,7 @@ int wbrt_destroy(wbrt_context *ctx)
 	for (auto &ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
 	if (ctx->render_done) (void)hipEventDestroy(ctx->render_done);
 	DevBuf *all[] = { &ctx->sph_geom, &ctx->sph_radius, &ctx->sph_mat_a, &ctx->sph_mat_b, &ctx->tri_geom,
-	                  &ctx->tri_mat_a, &ctx->tri_mat_b, &ctx->tri_orig, &ctx->box_min, &ctx->box_max,
+	                  &ctx->tri_shade, &ctx->mat_table, &ctx->tri_orig, &ctx->box_min, &ctx->box_max,
 	                  &ctx->box_range, &ctx->bvh_nodes[0], &ctx->bvh_tris[0], &ctx->bvh_roots[0],
 	                  &ctx->bvh_nodes[1], &ctx->bvh_tris[1], &ctx->bvh_roots[1], &ctx->bvh_pairs[0], &ctx->bvh_pairs[1], &ctx->bvh_mbox, &ctx->top_nodes, &ctx->top_box, &ctx->sky, &ctx->seeds, &ctx->image, &ctx->ids, &ctx->counters, &ctx->rgb8,
 	                  &ctx->costs, &ctx->tile_costs, &ctx->order, &ctx->hist };
@@ -397,8 +399,8 @@ int wbrt_upload_scene(wbrt_context *ctx, const wbrt_sphere *spheres, int32_t S,
 	}
 	for (int b = 0; b < B; ++b) first[(size_t)b + 1] += first[(size_t)b];
 	const int Tg = B ? first[(size_t)B] : 0;
-	std::vector<float4> tgeom((size_t)Tg * 3), tmat_a((size_t)Tg);
-	std::vector<float2> tmat_b((size_t)Tg);
+	std::vector<float4> tgeom((size_t)Tg * 3), tshade((size_t)Tg), mtable;
+	std::map<std::array<uint32_t, 6>, int> material_index; // distinct materials by bit pattern
 	std::vector<int> torig((size_t)Tg);
 	std::vector<int> cursor(first.begin(), first.end());
 	for (int j = 0; j < T; ++j)
@@ -412,9 +414,29 @@ int wbrt_upload_scene(wbrt_context *ctx, const wbrt_sphere *spheres, int32_t S,
 		tgeom[3 * k + 0] = make_float4(t.p0.x, t.p0.y, t.p0.z, e0x);
 		tgeom[3 * k + 1] = make_float4(e0y, e0z, e1x, e1y);
 		tgeom[3 * k + 2] = make_float4(e1z, 0.0f, 0.0f, 0.0f);
-		tmat_a[k] = make_float4(t.material.albedo.x, t.material.albedo.y, t.material.albedo.z, t.material.fuzz);
-		float ty; std::memcpy(&ty, &t.material.type, 4);
-		tmat_b[k] = make_float2(t.material.ior, ty);
+		// gpu_kernel.cl:524: outwardNormal = Unit(Cross(edge0, edge1)) = Cross / sqrt(x*x + y*y + z*z), every product, sum,
+		// root and quotient rounded once (the same float sequence the kernel would run per hit)
+		volatile float cx = e0y * e1z, cx2 = e0z * e1y, cy = e0z * e1x, cy2 = e0x * e1z, cz = e0x * e1y, cz2 = e0y * e1x;
+		volatile float nx = cx - cx2, ny = cy - cy2, nz = cz - cz2;
+		volatile float xx = nx * nx, yy = ny * ny, zz = nz * nz;
+		volatile float sxy = xx + yy;
+		volatile float len2 = sxy + zz;
+		volatile float len = std::sqrt(len2);
+		volatile float ux = nx / len, uy = ny / len, uz = nz / len;
+		std::array<uint32_t, 6> key;
+		const float mvals[5] = { t.material.albedo.x, t.material.albedo.y, t.material.albedo.z, t.material.fuzz, t.material.ior };
+		std::memcpy(key.data(), mvals, 20);
+		std::memcpy(&key[5], &t.material.type, 4);
+		auto found = material_index.find(key);
+		if (found == material_index.end())
+		{
+			found = material_index.emplace(key, (int)(mtable.size() / 2)).first;
+			float ty; std::memcpy(&ty, &t.material.type, 4);
+			mtable.push_back(make_float4(mvals[0], mvals[1], mvals[2], mvals[3]));
+			mtable.push_back(make_float4(mvals[4], ty, 0.0f, 0.0f));
+		}
+		float mi; std::memcpy(&mi, &found->second, 4);
+		tshade[k] = make_float4(ux, uy, uz, mi);
 		torig[k] = j;
 	}
 	std::vector<float4> bmin((size_t)B), bmax((size_t)B);
@@ -430,7 +452,7 @@ int wbrt_upload_scene(wbrt_context *ctx, const wbrt_sphere *spheres, int32_t S,
 	std::vector<float4> geom_padded(geom);
 	if (geom_padded.size() < 8) geom_padded.resize(8, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
 	UP(sph_geom, geom_padded); UP(sph_radius, radius); UP(sph_mat_a, mat_a); UP(sph_mat_b, mat_b);
-	UP(tri_geom, tgeom); UP(tri_mat_a, tmat_a); UP(tri_mat_b, tmat_b); UP(tri_orig, torig);
+	UP(tri_geom, tgeom); UP(tri_shade, tshade); UP(mat_table, mtable); UP(tri_orig, torig);
 	UP(box_min, bmin); UP(box_max, bmax); UP(box_range, brange);
 	ctx->top_depth = 0;
 	if (B >= ctx->box_tree_min)
@@ -574,8 +596,8 @@ int wbrt_upload_scene(wbrt_context *ctx, const wbrt_sphere *spheres, int32_t S,
 	sc.sph_mat_a = (const float4 *)ctx->sph_mat_a.p; sc.sph_mat_b = (const float2 *)ctx->sph_mat_b.p;
 	sc.S = S;
 	ctx->scene_generation++;
-	sc.tri_geom = (const float4 *)ctx->tri_geom.p; sc.tri_mat_a = (const float4 *)ctx->tri_mat_a.p;
-	sc.tri_mat_b = (const float2 *)ctx->tri_mat_b.p; sc.tri_orig = (const int *)ctx->tri_orig.p;
+	sc.tri_geom = (const float4 *)ctx->tri_geom.p; sc.tri_shade = (const float4 *)ctx->tri_shade.p;
+	sc.mat_table = (const float4 *)ctx->mat_table.p; sc.tri_orig = (const int *)ctx->tri_orig.p;
 	sc.T = Tg;
 	sc.box_min = (const float4 *)ctx->box_min.p; sc.box_max = (const float4 *)ctx->box_max.p;
 	sc.box_range = (const int2 *)ctx->box_range.p;

@@ -33,8 +33,11 @@ struct SceneDev
 	// triangles grouped by bounding-box index (stable), 12 floats each:
 	//   p0.xyz e0.x | e0.yz e1.xy | e1.z 0 0 0     with e0 = p1-p0, e1 = p2-p0
 	const float4 *tri_geom;   // [3*T']
-	const float4 *tri_mat_a;  // [T'] albedo.rgb, fuzz
-	const float2 *tri_mat_b;  // [T'] ior, type
+	// what shading a triangle hit needs, 16 bytes per triangle: the outward normal Unit(Cross(e0, e1)) of gpu_kernel.cl:524
+	// — it depends on the triangle only, so the upload evaluates the reference's float sequence once, IEEE-exact on the host —
+	// and the triangle's entry in the table of DISTINCT materials (meshes share one material, utility.cpp:99-170)
+	const float4 *tri_shade;  // [T'] normal.xyz, material index (int bits)
+	const float4 *mat_table;  // 2 per distinct material: albedo.rgb fuzz | ior type(int bits) - -
 	const int    *tri_orig;   // [T'] index in the caller's triangle array
 	int T;                    // T' = triangles whose boundingBoxId names an existing box
 	// bounding boxes
