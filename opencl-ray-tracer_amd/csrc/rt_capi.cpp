@@ -936,7 +936,11 @@ int wbrt_device_info(wbrt_context *ctx, char *buf, size_t buf_len)
 // Test and experiment hook (not in the public header): thresholds the library otherwise fixes.
 //   "lpt" 0/1 longest-first scheduling; "pilot_spp" samples of a pilot launch; "box_tree_min" /
 //   "sphere_tree_min" primitive counts from which the hierarchies over boxes / spheres are built (take
-//   effect at the next wbrt_upload_scene); "bvh_min_idle" idle lanes before a hand-over round.
+//   effect at the next wbrt_upload_scene); "bvh_min_idle" idle lanes before a hand-over round; "pilot_depth" bounce
+//   limit of a pilot launch; "strict_loop_max" triangle count up to which the proven-margin mode uses the cooperative
+//   loop; "wg_kernel" 0 / 4 / 8: scenes without meshes render with the workgroup kernel of that many waves that
+//   re-deals pixel streams between its waves (measured slower than the per-wave kernel; kept for that measurement),
+//   "wg_per_cu" its workgroups per compute unit (0: 6 of 4 waves, 3 of 8).
 // None of them changes a result.
 int wbrt_tune_(wbrt_context *ctx, const char *key, int value)
 {
@@ -949,8 +953,12 @@ int wbrt_tune_(wbrt_context *ctx, const char *key, int value)
 	else if (k == "sphere_tree_min") ctx->sphere_tree_min = value;
 	else if (k == "bvh_min_idle") ctx->bvh_steal_min_idle = value;
 	else if (k == "strict_loop_max") ctx->strict_loop_max = value;
-	else if (k == "wg_kernel") ctx->wg_kernel = value;
-	else if (k == "wg_per_cu") ctx->wg_per_cu = value;
+	else if (k == "wg_kernel")
+	{
+		if (value != 0 && value != 4 && value != 8) return fail(WBRT_ERR_INVALID, "wg_kernel takes 0, 4 or 8 (waves per workgroup)");
+		ctx->wg_kernel = value;
+	}
+	else if (k == "wg_per_cu") ctx->wg_per_cu = value > 0 && value <= 8 ? value : 0;
 	else return fail(WBRT_ERR_INVALID, "unknown tuning key " + k);
 	ctx->recorded_spp = 0;
 	return WBRT_OK;
