@@ -204,9 +204,15 @@ def test_mesh_modes_identical(gpu_ctx, name):
             for mode in (pkg.MESH_LOOP, pkg.MESH_BVH, pkg.MESH_BVH_CAPPED):
                 gpu_ctx.set_mesh_mode(mode)
                 images[mode] = gpu_ctx.render_frame(c)
+            # small meshes take the loop in the default mode: force the proven-margin walk on them as well
+            gpu_ctx.set_mesh_mode(pkg.MESH_BVH)
+            gpu_ctx.tune("strict_loop_max", 0)
+            images["forced walk"] = gpu_ctx.render_frame(c)
         finally:
+            gpu_ctx.tune("strict_loop_max", 4096)
             gpu_ctx.set_mesh_mode(pkg.MESH_BVH)
         assert np.array_equal(bits(images[pkg.MESH_BVH]), bits(images[pkg.MESH_LOOP]))
+        assert np.array_equal(bits(images["forced walk"]), bits(images[pkg.MESH_LOOP]))
         assert np.array_equal(bits(images[pkg.MESH_BVH_CAPPED]), bits(images[pkg.MESH_LOOP]))
     O = orc.Oracle(scene)
     assert np.array_equal(bits(images[pkg.MESH_LOOP]), bits(O.render_frame(c, seeds, threads=16)))
