@@ -171,7 +171,11 @@ int wbrt_make_seeds_device(wbrt_context *ctx, uint64_t base_seed, uint32_t shard
  * call, then += every shard's clamped sum), all on `stream`, asynchronously, without host synchronisation: seeds are
  * generated on the device.  shard_spp: samples per shard (num_shards entries), or NULL = camera->samplesPerPixel each.
  * With world > 1 the caller sums device_image over the ranks afterwards (wbrt_comm_allreduce_sum, or a collective of
- * its own when every rank is a process). */
+ * its own when every rank is a process).
+ * A rank's shards run as ONE kernel launch where their sample counts allow (2 to 8 shards, counts equal or dropping by
+ * one once, as wbrt_split_spp deals them; scenes without a hierarchy over their boxes): every lane renders its pixel's
+ * stream of each shard in turn and adds each sum to the pixel — the same sums in the same order as one accumulating
+ * launch per shard (which is what runs otherwise), bit for bit. */
 int wbrt_render_shards(wbrt_context *ctx, const wbrt_camera *camera, int32_t num_shards, const int32_t *shard_spp,
                        uint64_t base_seed, int32_t rank, int32_t world, void *device_image, void *stream);
 

@@ -88,6 +88,7 @@ struct wbrt_context
 	int bvh_depth[2] = {0, 0};
 	int mesh_mode = WBRT_MESH_BVH;
 	int bvh_steal_min_idle = 8;
+	int fuse_shards = 1;          // wbrt_render_shards renders a rank's shards in one launch where their sample counts allow
 	int wg_kernel = 0, wg_per_cu = 0; // opt-in: waves (4 or 8) of the workgroup render kernel for scenes without meshes, and its workgroups per CU
 	int strict_loop_max = 4096;   // proven-margin mode: meshes up to this many triangles use the cooperative loop
 	float bvh_rho = 2e-4f; // WBRT_MESH_BVH_CAPPED: box margin as a fraction of the ray's distance bound
@@ -129,6 +130,14 @@ int wait_renders(wbrt_context *ctx)
 	HIP_TRY(hipStreamSynchronize(ctx->stream));
 	ctx->render_busy = false;
 	return WBRT_OK;
+}
+
+// Whether render launches of this context walk the hierarchies built on upload (else: the loops over boxes and triangles).
+bool walks_hierarchies(const wbrt_context *ctx)
+{
+	// strict margins on a small mesh widen every box to the whole mesh: the cooperative loop is faster there
+	const bool strict_small = ctx->mesh_mode == WBRT_MESH_BVH && ctx->sc.T <= ctx->strict_loop_max && !ctx->have_sphere_tree;
+	return ctx->mesh_mode != WBRT_MESH_LOOP && ctx->have_bvh && !strict_small;
 }
 
 // Fills launch parameters from the camera; validates what the kernels assume.
@@ -174,9 +183,7 @@ int make_params(wbrt_context *ctx, const wbrt_camera *cam, bool whole_frame, Ren
 	p.wg = ctx->wg_kernel;
 	p.wg_per_cu = ctx->wg_per_cu;
 	p.sc = ctx->sc;
-	// strict margins on a small mesh widen every box to the whole mesh: the cooperative loop is faster there
-	const bool strict_small = ctx->mesh_mode == WBRT_MESH_BVH && ctx->sc.T <= ctx->strict_loop_max && !ctx->have_sphere_tree;
-	if (ctx->mesh_mode != WBRT_MESH_LOOP && ctx->have_bvh && !strict_small)
+	if (walks_hierarchies(ctx))
 	{
 		const int variant = ctx->mesh_mode == WBRT_MESH_BVH ? 1 : 0;
 		p.sc.bvh_nodes = ctx->bvh_ptr[variant][0];
@@ -241,9 +248,11 @@ int scheduled_launch(wbrt_context *ctx, const RenderParams &p, hipStream_t strea
 		if (rc) return rc;
 		q.next = (unsigned *)ctx->hist.p + 256;
 	}
+	// samples per pixel of the whole launch (fused seed shards: all of them)
+	const int launch_spp = p.n_shards > 1 ? p.n_shards * p.spp - (p.n_shards - p.n_full) : p.spp;
 	// a pilot takes at most an eighth of the launch's samples (short seed shards get a shorter pilot)
-	const int pilot_spp = std::max(1, std::min(ctx->pilot_spp, p.spp / 8));
-	if (ctx->lpt && total >= 65536 && total % 64 == 0 && p.spp >= 8)
+	const int pilot_spp = std::max(1, std::min(ctx->pilot_spp, launch_spp / 8));
+	if (ctx->lpt && total >= 65536 && total % 64 == 0 && launch_spp >= 8)
 	{
 		WbrtSchedule s;
 		if (fixed) s = *fixed;
@@ -280,6 +289,7 @@ int scheduled_launch(wbrt_context *ctx, const RenderParams &p, hipStream_t strea
 		{
 			RenderParams pilot = q;
 			pilot.spp = pilot_spp;
+			pilot.n_shards = 0; // the first shard's streams price the pixels
 			if (ctx->pilot_depth > 0 && ctx->pilot_depth < pilot.max_depth) pilot.max_depth = ctx->pilot_depth;
 			pilot.costs = s.costs;
 			pilot.out = nullptr;
@@ -292,7 +302,7 @@ int scheduled_launch(wbrt_context *ctx, const RenderParams &p, hipStream_t strea
 		{
 			q.record = s.costs;
 			std::memcpy(&ctx->recorded_view, &key, sizeof key);
-			ctx->recorded_spp = p.spp;
+			ctx->recorded_spp = launch_spp;
 		}
 		HIP_TRY(wbrt_launch_render(q, stream));
 	}
@@ -672,6 +682,54 @@ int wbrt_render_shards(wbrt_context *ctx, const wbrt_camera *camera, int32_t num
 	const size_t bytes = (size_t)camera->width * camera->height * 3 * sizeof(float);
 	const size_t block_px = (size_t)(int)camera->blockSize.x * (size_t)(int)camera->blockSize.y;
 	HIP_TRY(hipMemsetAsync(device_image, 0, bytes, (hipStream_t)stream));
+	// This rank's shards in ONE launch where possible (a lane renders its pixel's stream of every shard in turn and adds
+	// each sum to the pixel: the same sums in the same order as the launches below, without their start-up and drain):
+	// up to 8 shards whose sample counts are equal or drop by one once (wbrt_split_spp's pattern), at least 1 sample each.
+	{
+		std::vector<int32_t> mine;
+		for (int32_t v = rank; v < num_shards; v += world) mine.push_back(v);
+		const int n = (int)mine.size();
+		// (scenes with a hierarchy over their boxes keep one launch per shard: their render build has no fused form)
+		bool fusable = ctx->fuse_shards && n >= 2 && n <= 8 && !(ctx->top_depth > 0 && walks_hierarchies(ctx));
+		int first_spp = 0, n_full = n;
+		for (int k = 0; k < n && fusable; ++k)
+		{
+			const int spp = shard_spp ? shard_spp[mine[(size_t)k]] : camera->samplesPerPixel;
+			if (k == 0) first_spp = spp;
+			if (spp < 1) fusable = false;
+			else if (spp == first_spp) { if (n_full != n) fusable = false; }
+			else if (spp == first_spp - 1) { if (n_full == n) n_full = k; }
+			else fusable = false;
+		}
+		if (fusable && first_spp - (n_full < n ? 1 : 0) < 1) fusable = false;
+		if (fusable)
+		{
+			// all seed buffers side by side
+			const size_t all = block_px * (size_t)n;
+			if (all * sizeof(uint32_t) > ctx->seeds.bytes || !ctx->seeds.p)
+			{
+				rc = wait_renders(ctx);
+				if (rc) return rc;
+				ctx->n_seeds = 0;
+				rc = ctx->seeds.reserve(all * sizeof(uint32_t));
+				if (rc) return rc;
+			}
+			if (ctx->render_busy) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, ctx->render_done, 0));
+			for (int k = 0; k < n; ++k)
+				HIP_TRY(wbrt_launch_make_seeds(wbrt_seed_stream_state_(base_seed, (uint32_t)mine[(size_t)k]),
+				                               (uint32_t *)ctx->seeds.p + (size_t)k * block_px, block_px, (hipStream_t)stream));
+			ctx->n_seeds = all;
+			wbrt_camera c = *camera;
+			c.samplesPerPixel = first_spp;
+			RenderParams p;
+			rc = make_params(ctx, &c, true, p);
+			if (rc) return rc;
+			p.out = (float *)device_image;
+			p.out_mode = WBRT_OUT_ACCUMULATE;
+			p.n_shards = n; p.n_full = n_full; p.seeds_stride = (int)block_px;
+			return timed_launch(ctx, p, (hipStream_t)stream);
+		}
+	}
 	for (int32_t v = rank; v < num_shards; v += world)
 	{
 		wbrt_camera c = *camera;
@@ -938,7 +996,7 @@ int wbrt_device_info(wbrt_context *ctx, char *buf, size_t buf_len)
 //   "sphere_tree_min" primitive counts from which the hierarchies over boxes / spheres are built (take
 //   effect at the next wbrt_upload_scene); "bvh_min_idle" idle lanes before a hand-over round; "pilot_depth" bounce
 //   limit of a pilot launch; "strict_loop_max" triangle count up to which the proven-margin mode uses the cooperative
-//   loop; "wg_kernel" 0 / 4 / 8: scenes without meshes render with the workgroup kernel of that many waves that
+//   loop; "fuse_shards" 0/1: wbrt_render_shards uses one launch per rank where it can; "wg_kernel" 0 / 4 / 8: scenes without meshes render with the workgroup kernel of that many waves that
 //   re-deals pixel streams between its waves (measured slower than the per-wave kernel; kept for that measurement),
 //   "wg_per_cu" its workgroups per compute unit (0: 6 of 4 waves, 3 of 8).
 // None of them changes a result.
@@ -953,6 +1011,7 @@ int wbrt_tune_(wbrt_context *ctx, const char *key, int value)
 	else if (k == "sphere_tree_min") ctx->sphere_tree_min = value;
 	else if (k == "bvh_min_idle") ctx->bvh_steal_min_idle = value;
 	else if (k == "strict_loop_max") ctx->strict_loop_max = value;
+	else if (k == "fuse_shards") ctx->fuse_shards = value != 0;
 	else if (k == "wg_kernel")
 	{
 		if (value != 0 && value != 4 && value != 8) return fail(WBRT_ERR_INVALID, "wg_kernel takes 0, 4 or 8 (waves per workgroup)");

@@ -255,7 +255,7 @@ hipError_t wbrt_launch_render(const RenderParams &p, hipStream_t stream)
 {
 	const dim3 grid(grid_for(p, WBRT_RENDER_BLOCK)), block(WBRT_RENDER_BLOCK);
 	const bool box_tree = p.sc.top_nodes && p.sc.bvh_nodes, mesh = p.sc.B > 0 || (p.sc.sph_tree && p.sc.bvh_nodes);
-	if (p.wg && !mesh && p.spp > 0 && p.next)
+	if (p.wg && !mesh && p.spp > 0 && p.next && p.n_shards <= 1)
 	{
 		// opt-in form (measured slower than k_render on the headline frame; kept selectable for that measurement):
 		// persistent workgroups of p.wg waves, as many as the device holds at once (or fewer, for a small launch)
@@ -281,6 +281,22 @@ hipError_t wbrt_launch_render(const RenderParams &p, hipStream_t stream)
 		{
 			if (p.tolerant) hipLaunchKernelGGL(tolerant_impl::k_render_wg<256>, wg_grid, wg_block, 0, stream, p);
 			else hipLaunchKernelGGL(strict_impl::k_render_wg<256>, wg_grid, wg_block, 0, stream, p);
+		}
+		return hipGetLastError();
+	}
+	if (p.n_shards > 1)
+	{
+		// fused seed shards (accumulating launches of scenes without a hierarchy over the boxes; the caller checks)
+		if (box_tree || p.out_mode != 2 || !p.out || p.costs) return hipErrorInvalidValue;
+		if (p.tolerant)
+		{
+			if (mesh) hipLaunchKernelGGL((tolerant_impl::k_render<false, true, false, true>), grid, block, 0, stream, p);
+			else hipLaunchKernelGGL((tolerant_impl::k_render<false, false, false, true>), grid, block, 0, stream, p);
+		}
+		else
+		{
+			if (mesh) hipLaunchKernelGGL((strict_impl::k_render<false, true, false, true>), grid, block, 0, stream, p);
+			else hipLaunchKernelGGL((strict_impl::k_render<false, false, false, true>), grid, block, 0, stream, p);
 		}
 		return hipGetLastError();
 	}

@@ -474,6 +474,48 @@ def test_workgroup_kernel_equals_per_wave_kernel(waves):
                     assert np.array_equal(bits(ctx.render_frame(cam, mode)), bits(ref)), (arith, mode, reuse, "recorded")
 
 
+@pytest.mark.parametrize("name", ["readme", "mesh"])
+def test_fused_seed_shards_equal_one_launch_per_shard(name):
+    """wbrt_render_shards renders a rank's shards in one launch (a lane runs its pixel's stream of every shard in turn);
+    the accumulation buffer must hold exactly what one accumulating launch per shard leaves, for every split of the shards
+    over ranks, with the schedule taken from a pilot and from recorded costs, in both arithmetic modes."""
+    import torch
+    if name == "readme":
+        scene, cam = pkg.scene_readme(), pkg.camera_readme(384, 0, 50)
+    else:
+        scene, cam = scene_main_cpp_with_mesh("f1_car"), pkg.camera_main_cpp(384, 0, 50)
+    bw, bh = pkg.set_blocks(cam, 4)
+    spp = pkg.split_spp(45, 8)  # 6 6 6 6 6 5 5 5
+    cam.samplesPerPixel = max(spp)
+    buf = torch.zeros(cam.height * cam.width * 3, dtype=torch.float32, device="cuda:0")
+    with pkg.Context(0) as ctx:
+        ctx.upload_scene(scene)
+        for arith in (pkg.ARITH_STRICT, pkg.ARITH_TOLERANT):
+            ctx.set_arith_mode(arith)
+            for world in (1, 2, 3, 8):
+                for rank in range(world):
+                    got = {}
+                    for fuse in (0, 1, 1):  # the second fused frame is scheduled from the first one's recorded costs
+                        ctx.tune("fuse_shards", fuse)
+                        ctx.render_shards(cam, buf.data_ptr(), 8, 77, rank, world, spp)
+                        torch.cuda.synchronize()
+                        img = buf.cpu().numpy().copy()
+                        if fuse in got:
+                            assert np.array_equal(bits(img), bits(got[fuse])), (arith, world, rank, "recorded costs")
+                        got[fuse] = img
+                    assert np.array_equal(bits(got[1]), bits(got[0])), (arith, world, rank)
+        # sample counts outside the pattern that can be fused take the loop over the shards
+        odd = [3, 7, 1, 2, 2, 9, 4, 4]
+        cam.samplesPerPixel = max(odd)
+        ctx.set_arith_mode(pkg.ARITH_STRICT)
+        ctx.tune("fuse_shards", 0)
+        ctx.render_shards(cam, buf.data_ptr(), 8, 5, 0, 2, odd); torch.cuda.synchronize()
+        want = buf.cpu().numpy().copy()
+        ctx.tune("fuse_shards", 1)
+        ctx.render_shards(cam, buf.data_ptr(), 8, 5, 0, 2, odd); torch.cuda.synchronize()
+        assert np.array_equal(bits(buf.cpu().numpy()), bits(want))
+
+
 def test_launches_of_one_context_on_two_streams_are_ordered(gpu_ctx):
     """A context's schedule arrays and seed buffer are shared by its launches: a launch on another stream waits for the
     previous one (event recorded after every render launch), so alternating two streams gives the sequential images."""
