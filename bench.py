@@ -321,7 +321,12 @@ def main():
             ctx.set_mesh_mode(pkg.MESH_BVH)
 
     if rank == 0:
-        launch_spp = cam.samplesPerPixel if not sharded else total_spp / SHARDS
+        if sharded:
+            # a rank's shards run as one fused launch where the library can fuse them: samples per launch from the launches counted
+            rank_spp = sum(shard_spp[v] for v in pkg.shards_of_rank(SHARDS, 0, world))
+            launch_spp = rank_spp / max(launches / max(args.steps, 1), 1e-9)
+        else:
+            launch_spp = cam.samplesPerPixel
         launch_paths = cam.width * cam.height * launch_spp
         hw_note = None
         if args.config in ("mesh", "stress"):
@@ -353,8 +358,8 @@ def main():
             ctx.upload_seeds(seeds)
         else:
             count_cam = cam.copy()
-            count_cam.samplesPerPixel = max(1, int(round(launch_spp)))
-            counters = ctx.count_events(count_cam)  # exact event counts of one launch (untimed)
+            count_cam.samplesPerPixel = max(1, min(int(round(launch_spp)), 125))
+            counters = ctx.count_events(count_cam)  # exact event counts of (up to 125 spp of) one launch, untimed; scaled below
             flops = pkg.algorithmic_flops(counters) * (launch_spp / count_cam.samplesPerPixel)
             if nfl > 1:  # overlapping launches have no meaningful individual duration: price the frame rate instead
                 kernel_ms, launches = dt * 1e3, args.steps
@@ -375,8 +380,8 @@ def main():
                                 "%d ranks, spp split as seed shards + one all-reduce(sum) of the %.2f MB accumulation buffer per frame" % (
                                     world, cam.width * cam.height * 12 / 1e6)),
                 "kernel_ms_per_launch": round(k_ms, 4), "render_launches_per_step": round(launches / max(args.steps, 1), 2), "frames_in_flight": nfl,
-                "schedule": "waves launched costliest first; every timed step prices its pixel streams with its own 4-spp pilot launch "
-                            "(cold frame, nothing carried over from the previous step)" + ("; the shards of one frame share that schedule" if sharded else ""),
+                "schedule": "waves launched costliest first; every timed step prices its pixel streams with its own pilot launch (1 to 4 spp, at most "
+                            "a 24th of the launch's samples; cold frame, nothing carried over from the previous step)" + ("; the shards a rank renders share that schedule (one fused launch where their sample counts allow)" if sharded else ""),
                 "kernel_ms_per_launch_includes": "pilot launch + cost sort + render launch (HIP events on the launch stream)",
             },
             "roofline": {

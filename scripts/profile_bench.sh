@@ -5,6 +5,7 @@ set -u
 TAG=${1:-run}
 shift || true
 OUT=gpurun_out/prof_$TAG
+rm -rf $OUT
 mkdir -p $OUT
 cd /tmp 2>/dev/null && export TMPDIR=/tmp && cd - >/dev/null
 B="python3 bench.py --no-cpu-baseline --no-extras $*"
