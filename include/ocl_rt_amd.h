@@ -217,7 +217,7 @@ int wbrt_render_sharded_frame(wbrt_comm *comm, wbrt_context *const *ctxs, int32_
  * the leaves: the same boxes as its loop), and scenes with 48 or more spheres also walk a hierarchy over the spheres
  * (margins proven from the reference's float sphere test: same result as its loop over all
  * spheres, gpu_kernel.cl:361-371); WBRT_MESH_LOOP loops over all spheres as well.  In WBRT_MESH_BVH
- * meshes of at most 4096 triangles use the loop.
+ * meshes of at most 256 triangles use the loop.
  * Primary ids and event counters always use the loops.  Takes effect at the next render. */
 enum { WBRT_MESH_LOOP = 0, WBRT_MESH_BVH = 1, WBRT_MESH_BVH_CAPPED = 2 };
 int wbrt_set_mesh_mode(wbrt_context *ctx, int mode);

@@ -90,7 +90,8 @@ struct wbrt_context
 	int bvh_steal_min_idle = 8;
 	int fuse_shards = 1;          // wbrt_render_shards renders a rank's shards in one launch where their sample counts allow
 	int wg_kernel = 0, wg_per_cu = 0; // opt-in: waves (4 or 8) of the workgroup render kernel for scenes without meshes, and its workgroups per CU
-	int strict_loop_max = 4096;   // proven-margin mode: meshes up to this many triangles use the cooperative loop
+	int strict_loop_max = 256;    // proven-margin mode: meshes up to this many triangles use the cooperative loop (measured crossover:
+	                              // 256 triangles 15.7 vs 15.1 ms, 128: 6.1 vs 9.1 ms, 512: 31.6 vs 21.8 ms, loop vs walk)
 	float bvh_rho = 2e-4f; // WBRT_MESH_BVH_CAPPED: box margin as a fraction of the ray's distance bound
 	DevBuf sky, seeds, image, ids, counters, rgb8, costs, tile_costs, order, hist;
 	int lpt = 1;        // longest-first scheduling from a pilot pass

@@ -2,7 +2,7 @@
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from util import pkg, scene_main_cpp_with_mesh, bits
-W = int(sys.argv[1]); SPP = int(sys.argv[2]); mesh = sys.argv[3]; loop_max = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
+W = int(sys.argv[1]); SPP = int(sys.argv[2]); mesh = sys.argv[3]; loop_max = int(sys.argv[4]) if len(sys.argv) > 4 else 256
 scene = scene_main_cpp_with_mesh(mesh)
 cam = pkg.camera_main_cpp(W, SPP, 50)
 bw, bh = pkg.set_blocks(cam, 4)

@@ -209,7 +209,7 @@ def test_mesh_modes_identical(gpu_ctx, name):
             gpu_ctx.tune("strict_loop_max", 0)
             images["forced walk"] = gpu_ctx.render_frame(c)
         finally:
-            gpu_ctx.tune("strict_loop_max", 4096)
+            gpu_ctx.tune("strict_loop_max", 256)
             gpu_ctx.set_mesh_mode(pkg.MESH_BVH)
         assert np.array_equal(bits(images[pkg.MESH_BVH]), bits(images[pkg.MESH_LOOP]))
         assert np.array_equal(bits(images["forced walk"]), bits(images[pkg.MESH_LOOP]))
