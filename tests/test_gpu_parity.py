@@ -2,6 +2,7 @@
 golden vectors.  Bar: bit-exact primary-hit ids; images bit-exact against the oracle in its
 portable-math mode and within MAE <= 1e-3 / PSNR >= 40 dB of the reference's golden images
 (they differ only where atan2/asin last bits flip a sky texel)."""
+import os
 import numpy as np
 import pytest
 
@@ -734,7 +735,7 @@ def test_sphere_scan_on_adversarial_scenes(gpu_ctx, name):
     assert gc == dict(zip(pkg.COUNTER_NAMES, map(int, oc)))
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("WBRT_TEST_SPHERE_SEEDS", "12"))))
 def test_random_sphere_scenes(gpu_ctx, seed):
     """Random overlapping spheres of all four material types, random cameras (half of them with defocus):
     image and primary ids against the oracle, bit for bit."""
@@ -759,7 +760,7 @@ def test_random_sphere_scenes(gpu_ctx, seed):
     assert np.array_equal(gpu_ctx.primary_ids(cam), O.primary_ids(cam, seeds))
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("WBRT_TEST_MESH_SEEDS", "6"))))
 def test_random_mesh_scenes(gpu_ctx, seed):
     """Random triangle soups (sizes over three decades, sliver triangles among them) in 1-5 bounding boxes plus
     random spheres: the three mesh modes agree bit for bit and the loop mode equals the oracle."""
@@ -794,9 +795,14 @@ def test_random_mesh_scenes(gpu_ctx, seed):
         for mode in (pkg.MESH_LOOP, pkg.MESH_BVH, pkg.MESH_BVH_CAPPED):
             gpu_ctx.set_mesh_mode(mode)
             images[mode] = gpu_ctx.render_frame(cam)
+        gpu_ctx.set_mesh_mode(pkg.MESH_BVH)
+        gpu_ctx.tune("strict_loop_max", 0)  # the proven-margin walk on the small soups as well
+        images["forced walk"] = gpu_ctx.render_frame(cam)
     finally:
+        gpu_ctx.tune("strict_loop_max", 256)
         gpu_ctx.set_mesh_mode(pkg.MESH_BVH)
     assert np.array_equal(bits(images[pkg.MESH_BVH]), bits(images[pkg.MESH_LOOP]))
+    assert np.array_equal(bits(images["forced walk"]), bits(images[pkg.MESH_LOOP]))
     assert np.array_equal(bits(images[pkg.MESH_BVH_CAPPED]), bits(images[pkg.MESH_LOOP]))
     O = orc.Oracle(scene)
     assert np.array_equal(bits(images[pkg.MESH_LOOP]), bits(O.render_frame(cam, seeds)))
