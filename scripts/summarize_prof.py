@@ -44,6 +44,10 @@ for d in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write", "pmc_tcp"):
         print("  kernel %s" % k[:70])
         for c, vals in sorted(ctrs.items()):
             print("    %-28s %18.1f  (n=%d, max %.1f)" % (c, sum(vals) / len(vals), len(vals), max(vals)))
+        if "SQ_THREAD_CYCLES_VALU" in ctrs and "SQ_ACTIVE_INST_VALU" in ctrs and max(ctrs["SQ_ACTIVE_INST_VALU"]) > 0:
+            # of the largest dispatch (the full render launch)
+            print("    %-28s %18.3f  (SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU), largest dispatch)" % (
+                "active lanes per VALU inst", max(ctrs["SQ_THREAD_CYCLES_VALU"]) / (64.0 * max(ctrs["SQ_ACTIVE_INST_VALU"]))))
 
 # HBM bytes of one full render launch for bench.py's roofline.traffic: WRITE_SIZE + 2 x FETCH_SIZE of the largest
 # dispatch (both counters are in KB; gfx950 tallies wide reads at half their bytes, so the doubled figure is an upper bound)
