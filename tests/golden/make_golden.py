@@ -322,6 +322,12 @@ def tolerance_case():
     image_case("readme_320x180_s250_b4", pkg.scene_readme(), pkg.camera_readme(320, 250, 50), 4, 33)
 
 
+def stress_case():
+    """The divergence-stress scene in small (60 spheres, 4608 triangles in 36 bounding boxes) from the reference kernel: many
+    boxes and many spheres at once, which the other image cases do not have."""
+    image_case("stress_128x72_s4_b4", pkg.scene_stress(60, 48, 48, 6, 6), pkg.camera_stress(128, 4, 50), 4, 17)
+
+
 def main():
     if not orc.have_ref():
         raise SystemExit("oracle/_ref/libwbref.so missing: run `make -C oracle ref` where /root/reference exists")
@@ -333,6 +339,9 @@ def main():
         return
     if "--tolerance" in sys.argv:
         tolerance_case()
+        return
+    if "--stress" in sys.argv:
+        stress_case()
         return
     if "--host-only" in sys.argv:
         host_kat()

@@ -86,7 +86,7 @@ def test_device_rng_matches_golden(gpu_ctx):
 
 
 IMAGE_CASES = ["readme_160x90_s8_b4", "readme_160x90_s8_b1", "readme_64x36_s250_b4",
-               "maincpp_160x90_s8_b4", "maincpp_f1car_96x54_s2_b4"]
+               "maincpp_160x90_s8_b4", "maincpp_f1car_96x54_s2_b4", "stress_128x72_s4_b4"]
 
 
 @pytest.mark.parametrize("tag", IMAGE_CASES)

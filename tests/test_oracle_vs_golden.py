@@ -128,7 +128,7 @@ def test_portable_math_accuracy():
 
 
 IMAGE_CASES = ["readme_160x90_s8_b4", "readme_160x90_s8_b1", "readme_64x36_s250_b4",
-               "maincpp_160x90_s8_b4", "maincpp_f1car_96x54_s2_b4"]
+               "maincpp_160x90_s8_b4", "maincpp_f1car_96x54_s2_b4", "stress_128x72_s4_b4"]
 
 
 @pytest.mark.parametrize("tag", IMAGE_CASES)

@@ -39,12 +39,16 @@ def scene_by_tag(tag):
         return scene_main_cpp_with_mesh("f1_car")
     if tag.startswith("maincpp"):
         return pkg.scene_main_cpp()
+    if tag.startswith("stress"):
+        return pkg.scene_stress(60, 48, 48, 6, 6)
     raise KeyError(tag)
 
 
 def camera_by_meta(meta):
     if meta["tag"].startswith("readme"):
         cam = pkg.camera_readme(meta["width"], meta["spp"], meta["depth"])
+    elif meta["tag"].startswith("stress"):
+        cam = pkg.camera_stress(meta["width"], meta["spp"], meta["depth"])
     else:
         cam = pkg.camera_main_cpp(meta["width"], meta["spp"], meta["depth"])
     bw, bh = pkg.set_blocks(cam, meta["blocks"])
