@@ -6,14 +6,14 @@ pixel, depth 50, 4 blocks (the reference's default tiling), on N MI355X.
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One step = one frame: path-trace every pixel-sample on the GPU (inputs already resident in
-HBM), sum the un-normalised accumulation buffers over ranks (RCCL all-reduce, N > 1 only),
-normalise + gamma to 8-bit on the device.
+HBM), sum the un-normalised accumulation buffers over ranks onto rank 0 (RCCL reduce, N > 1 only),
+normalise + gamma to 8-bit on the device (rank 0).
 
   N = 1   the frame is ONE launch with the reference's semantics (one random stream per pixel, 250 samples);
           every step is a COLD frame: its launch schedule comes from its own pilot launch, nothing is carried
           over from the previous step (config.ms_per_step_schedule_carried_over reports the other case);
   N > 1   strong scaling on the SAME frame: 250 samples per pixel as 8 seed shards of 32/31 samples, shard v
-          rendered by rank v % N, one all-reduce(sum) of the 11 MB accumulation buffer per frame
+          rendered by rank v % N, one reduce(sum) of the 11 MB accumulation buffer to rank 0 per frame
           (--weak: every rank renders its own 250-spp shard instead, the frame then holds 250*N samples).
 
 The JSON line also carries
@@ -80,6 +80,72 @@ def cpu_baseline(pkg, scene, cam, seeds, whole_blocks):
     }
 
 
+def make_workload(pkg, config):
+    """Scene, camera, samples per pixel, description and whether the frame is always cut into seed shards, for one of
+    BASELINE.json's configurations."""
+    if config == "mesh":
+        soup = np.load(os.path.join(ROOT, "tests", "golden", "meshes.npz"))["f1_car"]  # parsed vertex soup of the reference's f1_car.obj (data)
+        scene = pkg.scene_main_cpp_from_soup(soup)
+        total_spp = 100
+        cam = pkg.camera_main_cpp(1920, total_spp, DEPTH)
+        name = "main.cpp scene: 8 spheres + f1_car mesh (15329 triangles, 1 bounding box), 1920x1080, 100 spp, depth 50, 4 blocks of 960x540 (BASELINE.json configs[2])"
+        return scene, cam, total_spp, name, False
+    if config == "uhd":
+        total_spp = 1000
+        name = "README 5-sphere scene, 3840x2160, 1000 spp, depth 50, 4 blocks of 1920x1080 (BASELINE.json configs[3])"
+        return pkg.scene_readme(), pkg.camera_readme(3840, total_spp, DEPTH), total_spp, name, True
+    if config == "stress":
+        total_spp = 500
+        name = ("divergence stress: 500 random Lambertian/metal spheres + 100352-triangle mesh in 256 bounding boxes, 3840x2160, "
+                "500 spp, depth 50, 4 blocks of 1920x1080 (BASELINE.json configs[4])")
+        return pkg.scene_stress(500, 224, 224, 16, 16), pkg.camera_stress(3840, total_spp, DEPTH), total_spp, name, True
+    name = "README 5-sphere scene, 1280x720, 250 spp, depth 50, 4 blocks of 640x360, bit-matched 48-bit LCG streams (BASELINE.json configs[1])"
+    return pkg.scene_readme(), pkg.camera_readme(WIDTH, SPP, DEPTH), SPP, name, False
+
+
+def other_config_step_ms(pkg, mg, torch, config, steps, device):
+    """ms per COLD step of another BASELINE configuration on one GPU, measured the way the headline is (wall clock around
+    `steps` frames, inputs resident, tone map included), in a context of its own: {"ms_per_step", "steps", "Mpaths/s"}."""
+    scene, cam, total_spp, _, always_sharded = make_workload(pkg, config)
+    bw, bh = pkg.set_blocks(cam, BLOCKS)
+    ctx = pkg.Context(device)
+    try:
+        ctx.upload_scene(scene)
+        ctx.upload_seeds(pkg.make_seeds(bw * bh, BASE_SEED))
+        frame = mg.FrameBuffers(cam.width, cam.height, torch.device("cuda", device))
+        stream = torch.cuda.current_stream().cuda_stream
+        shard_spp = pkg.split_spp(total_spp, SHARDS) if always_sharded else None
+        if always_sharded:
+            cam.samplesPerPixel = max(shard_spp)
+
+        def step(c):
+            if always_sharded:
+                ctx.set_schedule_reuse(True)  # forgets the recorded costs: the frame's first shard runs a pilot
+                mg.render_sharded_frame(ctx, c, frame, SHARDS, BASE_SEED, 0, 1, stream=stream, shard_spp=shard_spp)
+            else:
+                mg.render_step(ctx, c, frame, total_spp=total_spp, stream=stream)
+        if not always_sharded:
+            ctx.set_schedule_reuse(False)
+        # untimed: the same frame at 1 sample per launch (loads the kernels, grows the context's buffers)
+        warm = cam.copy()
+        warm.samplesPerPixel = 1
+        if always_sharded:
+            saved, shard_spp = shard_spp, [1] * SHARDS
+            step(warm)
+            shard_spp = saved
+        else:
+            step(warm)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(steps):
+            step(cam)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t) / steps * 1e3
+        return {"ms_per_step": round(ms, 3), "steps": steps, "Mpaths/s": round(cam.width * cam.height * total_spp / ms / 1e3, 1)}
+    finally:
+        ctx.close()
+
+
 def profiled_traffic(config):
     """HBM bytes per launch of the render kernel from the committed PMC summary of this configuration
     (profiles/r2/traffic.json, condensed from rocprofv3 --pmc passes), or None."""
@@ -140,32 +206,7 @@ def main():
 
     pkg = entry.load_package()
     mg = __import__("importlib").import_module(entry.PKG_NAME + ".multi_gpu")
-    if args.config == "mesh":
-        soup = np.load(os.path.join(ROOT, "tests", "golden", "meshes.npz"))["f1_car"]  # parsed vertex soup of the reference's f1_car.obj (data)
-        scene = pkg.scene_main_cpp_from_soup(soup)
-        total_spp = 100
-        cam = pkg.camera_main_cpp(1920, total_spp, DEPTH)
-        name = "main.cpp scene: 8 spheres + f1_car mesh (15329 triangles, 1 bounding box), 1920x1080, 100 spp, depth 50, 4 blocks of 960x540 (BASELINE.json configs[2])"
-        always_sharded = False
-    elif args.config == "uhd":
-        scene = pkg.scene_readme()
-        total_spp = 1000
-        cam = pkg.camera_readme(3840, total_spp, DEPTH)
-        name = "README 5-sphere scene, 3840x2160, 1000 spp, depth 50, 4 blocks of 1920x1080 (BASELINE.json configs[3])"
-        always_sharded = True
-    elif args.config == "stress":
-        scene = pkg.scene_stress(500, 224, 224, 16, 16)
-        total_spp = 500
-        cam = pkg.camera_stress(3840, total_spp, DEPTH)
-        name = ("divergence stress: 500 random Lambertian/metal spheres + 100352-triangle mesh in 256 bounding boxes, 3840x2160, "
-                "500 spp, depth 50, 4 blocks of 1920x1080 (BASELINE.json configs[4])")
-        always_sharded = True
-    else:
-        scene = pkg.scene_readme()
-        total_spp = SPP
-        cam = pkg.camera_readme(WIDTH, total_spp, DEPTH)
-        name = "README 5-sphere scene, 1280x720, 250 spp, depth 50, 4 blocks of 640x360, bit-matched 48-bit LCG streams (BASELINE.json configs[1])"
-        always_sharded = False
+    scene, cam, total_spp, name, always_sharded = make_workload(pkg, args.config)
     bw, bh = pkg.set_blocks(cam, BLOCKS)
     # how the frame is cut
     weak = args.weak and world > 1 and not always_sharded
@@ -213,21 +254,31 @@ def main():
             dist.all_reduce(h, op=op)
             t.copy_(h)
 
+    def frame_reduce(t):
+        # only rank 0 keeps the picture: a reduce to it moves half of what an all-reduce moves over xGMI
+        if backend == "nccl":
+            dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+        else:  # rehearsal backend: stage through the host
+            h = t.cpu()
+            dist.reduce(h, dst=0, op=dist.ReduceOp.SUM)
+            if rank == 0:
+                t.copy_(h)
+
     def step():
         if sharded:
             if cold[0]:
                 ctx.set_schedule_reuse(True)  # forgets the recorded costs: the frame's first shard runs a pilot, its other shards reuse it
             mg.render_sharded_frame(ctx, cam, frame, SHARDS, BASE_SEED, rank, world, stream=stream,
-                                    all_reduce=all_reduce if world > 1 else None, shard_spp=shard_spp)
+                                    all_reduce=frame_reduce if world > 1 else None, shard_spp=shard_spp, tonemap=rank == 0)
         elif nfl == 1:
             mg.render_step(ctx, cam, frame, total_spp=total_spp * world, stream=stream,
-                           all_reduce=all_reduce if world > 1 else None)
+                           all_reduce=frame_reduce if world > 1 else None, tonemap=rank == 0)
         else:
             k = step_no[0] % nfl
             step_no[0] += 1
             with torch.cuda.stream(streams[k]):
                 mg.render_step(ctxs[k], cam, frames[k], total_spp=total_spp * world, stream=streams[k].cuda_stream,
-                               all_reduce=all_reduce if world > 1 else None)
+                               all_reduce=frame_reduce if world > 1 else None, tonemap=rank == 0)
 
     def barrier():
         torch.cuda.synchronize()
@@ -377,7 +428,7 @@ def main():
                               else "WBRT_ARITH_TOLERANT (images within MAE 1e-3 / PSNR 40 dB of the reference, not bit-exact)",
                 "paths_per_step": paths_per_step,
                 "parallelism": ("1 GPU" if world == 1 else
-                                "%d ranks, spp split as seed shards + one all-reduce(sum) of the %.2f MB accumulation buffer per frame" % (
+                                "%d ranks, spp split as seed shards + one reduce(sum) of the %.2f MB accumulation buffer to rank 0 per frame" % (
                                     world, cam.width * cam.height * 12 / 1e6)),
                 "kernel_ms_per_launch": round(k_ms, 4), "render_launches_per_step": round(launches / max(args.steps, 1), 2), "frames_in_flight": nfl,
                 "schedule": "waves launched costliest first; every timed step prices its pixel streams with its own pilot launch (1 to 4 spp, at most "
@@ -400,6 +451,11 @@ def main():
         if args.config in ("mesh", "stress"):
             result["config"]["mesh_mode"] = "WBRT_MESH_BVH (default: hierarchy walk with proven margins, same result as the reference's triangle loop)"
             result["config"]["reference_equivalent_tflops"] = round(flops / (k_ms * 1e-3) / 1e12, 2)
+        if world == 1 and args.config == "readme" and args.arith == "strict" and nfl == 1 and not args.no_extras:
+            # the other BASELINE configurations on this GPU, cold steps, outside the timed region (each also has a bench line of
+            # its own: --config mesh / uhd / stress)
+            result["config"]["other_configs"] = {
+                c: other_config_step_ms(pkg, mg, torch, c, n, local_rank) for c, n in (("mesh", 3), ("uhd", 2), ("stress", 1))}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(pkg, scene, cam.copy(), seeds, whole_blocks=args.config in ("readme", "uhd"))
         print(json.dumps(result), flush=True)

@@ -164,7 +164,10 @@ int32_t wbrt_split_spp(int32_t total_spp, int32_t num_shards, int32_t *shard_spp
 
 /* wbrt_make_seeds + wbrt_upload_seeds without the host: the n seeds of (base_seed, shard) are generated on the
  * device into the context's seed buffer, on `stream` (bit-identical to wbrt_make_seeds).  Replaces main.cpp:148-152
- * + :166,183 for shard renders. */
+ * + :166,183 for shard renders.  The generated seeds REPLACE whatever wbrt_upload_seeds put there (like a second
+ * blocking write of main.cpp:183 would).  Ordering: every later launch of this context that reads the seeds, on any
+ * stream, waits for the generation (as after the reference's blocking upload, a caller may rely on "generated, then
+ * rendered"). */
 int wbrt_make_seeds_device(wbrt_context *ctx, uint64_t base_seed, uint32_t shard, size_t n, void *stream);
 
 /* Renders the shards of `rank` (of `world`) of one frame into device_image (width*height*3 floats, zeroed by the
@@ -172,6 +175,9 @@ int wbrt_make_seeds_device(wbrt_context *ctx, uint64_t base_seed, uint32_t shard
  * generated on the device.  shard_spp: samples per shard (num_shards entries), or NULL = camera->samplesPerPixel each.
  * With world > 1 the caller sums device_image over the ranks afterwards (wbrt_comm_allreduce_sum, or a collective of
  * its own when every rank is a process).
+ * Side effect: the context's seed buffer afterwards holds the seeds of this rank's shards, not what wbrt_upload_seeds
+ * put there; upload again before a render that is to use other seeds.  Arguments are validated before device_image
+ * is touched.
  * A rank's shards run as ONE kernel launch where their sample counts allow (2 to 8 shards, counts equal or dropping by
  * one once, as wbrt_split_spp deals them; scenes without a hierarchy over their boxes): every lane renders its pixel's
  * stream of each shard in turn and adds each sum to the pixel — the same sums in the same order as one accumulating
@@ -189,9 +195,12 @@ int32_t wbrt_comm_size(const wbrt_comm *comm);
  * on streams[i] (NULL array = default streams): the exchange step of a sharded frame, once per frame
  * (count = width*height*3: 11.06 MB at 1280x720).  Asynchronous. */
 int wbrt_comm_allreduce_sum(wbrt_comm *comm, void *const *device_buffers, size_t count, void *const *streams);
+/* The same exchange when only ONE GPU needs the frame (it tone-maps and writes the picture, as the single device of
+ * main.cpp:249-265 does): reduce(sum) to buffer `root`; the other buffers are left undefined.  Asynchronous. */
+int wbrt_comm_reduce_sum(wbrt_comm *comm, void *const *device_buffers, size_t count, int32_t root, void *const *streams);
 /* One sharded frame on n GPUs driven by this thread (replaces the block loop main.cpp:229-247 for multi-GPU hosts):
  * context i (on device i of the communicator) renders the shards v % n == i into its own device buffer, all GPUs
- * concurrently; one all-reduce(sum); host_sum (width*height*3 floats, row 0 = bottom) receives the frame's clamped
+ * concurrently; one reduce(sum) to GPU 0; host_sum (width*height*3 floats, row 0 = bottom) receives the frame's clamped
  * per-sample SUM over all shards (divide by the total sample count for the picture).  Blocking.  comm may be NULL
  * when n == 1.  Every context must hold the scene and the sky. */
 int wbrt_render_sharded_frame(wbrt_comm *comm, wbrt_context *const *ctxs, int32_t n, const wbrt_camera *camera,

@@ -90,6 +90,7 @@ def build(force=False):
 _lib = None
 MESH_LOOP, MESH_BVH, MESH_BVH_CAPPED = 0, 1, 2
 ARITH_STRICT, ARITH_TOLERANT = 0, 1
+ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_IO, ERR_CANCELLED = -1, -2, -3, -4, -5, -6
 
 # name -> (restype, argtypes); every symbol declared in include/ocl_rt_amd.h
 _P = C.c_void_p
@@ -117,6 +118,7 @@ _SIGNATURES = {
     "wbrt_comm_destroy": (C.c_int, [_P]),
     "wbrt_comm_size": (C.c_int32, [_P]),
     "wbrt_comm_allreduce_sum": (C.c_int, [_P, _P, C.c_size_t, _P]),
+    "wbrt_comm_reduce_sum": (C.c_int, [_P, _P, C.c_size_t, C.c_int32, _P]),
     "wbrt_render_sharded_frame": (C.c_int, [_P, _P, C.c_int32, C.POINTER(Camera), C.c_int32, _P, C.c_uint64, _P]),
     "wbrt_set_mesh_mode": (C.c_int, [_P, C.c_int]),
     "wbrt_set_schedule_reuse": (C.c_int, [_P, C.c_int]),
@@ -177,6 +179,10 @@ def lib():
         l.wbrt_math_probe_.argtypes = [_P, C.c_int, _P, _P, _P, C.c_int32]
         l.wbrt_tune_.restype = C.c_int
         l.wbrt_tune_.argtypes = [_P, C.c_char_p, C.c_int]
+        l.wbrt_buffer_bytes_.restype = C.c_longlong
+        l.wbrt_buffer_bytes_.argtypes = [_P, C.c_char_p]
+        l.wbrt_rccl_probe_.restype = C.c_int
+        l.wbrt_rccl_probe_.argtypes = [C.c_char_p]
         _lib = l
     return _lib
 
@@ -487,6 +493,13 @@ class Context:
         """Private test/experiment hook (wbrt_tune_): thresholds that never change a result."""
         _check(lib().wbrt_tune_(self._h, key.encode(), int(value)))
 
+    def buffer_bytes(self, name):
+        """Test hook: bytes the context has allocated for one of its schedule buffers (costs, tile_costs, order, hist)."""
+        v = lib().wbrt_buffer_bytes_(self._h, name.encode())
+        if v < 0:
+            raise ValueError(name)
+        return int(v)
+
     def make_seeds_device(self, n, base_seed=0x5EED, shard=0, stream=None):
         """Generates the seed buffer of (base_seed, shard) on the device (== make_seeds + upload_seeds, no host copy)."""
         _check(lib().wbrt_make_seeds_device(self._h, base_seed, shard, n, C.c_void_p(stream) if stream else None))
@@ -575,6 +588,11 @@ def render_sharded_frame(ctxs, cam, num_shards, base_seed=0x5EED, shard_spp=None
     return out
 
 
+def rccl_probe(library_name):
+    """Test hook: what wbrt_comm_create does when RCCL is to be loaded from `library_name` (raises WbrtError if it cannot)."""
+    _check(lib().wbrt_rccl_probe_(library_name.encode()))
+
+
 class Comm:
     """One process, several GPUs: RCCL communicator of the C ABI (wbrt_comm_*)."""
 
@@ -589,6 +607,11 @@ class Comm:
         bufs = (C.c_void_p * self.size)(*[C.c_void_p(p) for p in device_ptrs])
         st = None if streams is None else (C.c_void_p * self.size)(*[C.c_void_p(x) if x else None for x in streams])
         _check(lib().wbrt_comm_allreduce_sum(self._h, bufs, count, st))
+
+    def reduce_sum(self, device_ptrs, count, root=0, streams=None):
+        bufs = (C.c_void_p * self.size)(*[C.c_void_p(p) for p in device_ptrs])
+        st = None if streams is None else (C.c_void_p * self.size)(*[C.c_void_p(x) if x else None for x in streams])
+        _check(lib().wbrt_comm_reduce_sum(self._h, bufs, count, root, st))
 
     def close(self):
         if self._h:

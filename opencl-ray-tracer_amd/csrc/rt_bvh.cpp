@@ -345,22 +345,6 @@ struct MarginBuilder
 			}
 		}
 		int mid = -1;
-		// Size classes first: while a minority of the range is much larger than the rest (E above a quarter of the
-		// largest), it gets a subtree of its own, so that its margins do not widen the boxes of the majority.  The
-		// one-level pricing below does not see that gain, which only shows further down.
-		if (getenv("WBRT_PEEL") ? atoi(getenv("WBRT_PEEL")) : 0)
-		if (count > 4 * kLeaf && all.e > 0.0 && std::isfinite(all.e))
-		{
-			const double cut = all.e / 4.0;
-			int big = 0;
-			for (int i = first; i < first + count; ++i) big += prims[(size_t)i].e > cut;
-			if (big > 0 && 2 * big <= count && depth + 1 + balanced_levels(count - big) <= depth_limit)
-			{
-				auto it = std::partition(prims.begin() + first, prims.begin() + first + count, [&](const Prim &p) { return !(p.e > cut); });
-				mid = (int)(it - prims.begin());
-				best_key = -1;
-			}
-		}
 		if (best_key >= 0)
 		{
 			auto it = std::partition(prims.begin() + first, prims.begin() + first + count, [&](const Prim &p) {

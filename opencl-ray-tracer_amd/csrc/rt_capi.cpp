@@ -111,6 +111,10 @@ struct wbrt_context
 	size_t events_used = 0;
 	hipEvent_t render_done = nullptr; // recorded after every render launch: the launch's use of the context's buffers ends there
 	bool render_busy = false;
+	hipStream_t render_stream = nullptr; // the stream render_done was last recorded on
+	hipEvent_t seeds_ready = nullptr; // recorded after a device-side seed generation: launches on other streams wait for it
+	bool seeds_pending = false;
+	hipStream_t seeds_stream = nullptr;
 	int arith_mode = 0;
 };
 
@@ -127,9 +131,31 @@ int bind(wbrt_context *ctx)
 // contexts and streams of the device keep running).
 int wait_renders(wbrt_context *ctx)
 {
+	// every launch waits for its predecessor on another stream (await_inputs), so the last event covers all of them
 	if (ctx->render_busy) HIP_TRY(hipEventSynchronize(ctx->render_done));
+	if (ctx->seeds_pending) HIP_TRY(hipEventSynchronize(ctx->seeds_ready));
 	HIP_TRY(hipStreamSynchronize(ctx->stream));
 	ctx->render_busy = false;
+	ctx->seeds_pending = false;
+	return WBRT_OK;
+}
+
+// Before a launch that reads the context's buffers is enqueued on `stream`: the seeds a device-side generation is still
+// writing on another stream, and the previous render launch of this context on another stream (it shares the seed buffer
+// and, when scheduled, the schedule arrays; an upload that follows waits for the LAST launch only).
+int await_inputs(wbrt_context *ctx, hipStream_t stream)
+{
+	if (ctx->seeds_pending && ctx->seeds_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, ctx->seeds_ready, 0));
+	if (ctx->render_busy && ctx->render_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, ctx->render_done, 0));
+	return WBRT_OK;
+}
+
+// After a device-side seed generation was enqueued on `stream`.
+int seeds_generated(wbrt_context *ctx, hipStream_t stream)
+{
+	HIP_TRY(hipEventRecord(ctx->seeds_ready, stream));
+	ctx->seeds_pending = true;
+	ctx->seeds_stream = stream;
 	return WBRT_OK;
 }
 
@@ -142,7 +168,7 @@ bool walks_hierarchies(const wbrt_context *ctx)
 }
 
 // Fills launch parameters from the camera; validates what the kernels assume.
-int make_params(wbrt_context *ctx, const wbrt_camera *cam, bool whole_frame, RenderParams &p)
+int make_params(wbrt_context *ctx, const wbrt_camera *cam, bool whole_frame, RenderParams &p, bool check_seeds = true)
 {
 	if (!cam) return fail(WBRT_ERR_INVALID, "null camera");
 	if (!ctx->have_scene) return fail(WBRT_ERR_INVALID, "no scene uploaded (wbrt_upload_scene)");
@@ -151,7 +177,7 @@ int make_params(wbrt_context *ctx, const wbrt_camera *cam, bool whole_frame, Ren
 	if (bsx <= 0 || bsy <= 0) return fail(WBRT_ERR_INVALID, "camera.blockSize must be positive");
 	if (cam->width <= 0 || cam->height <= 0) return fail(WBRT_ERR_INVALID, "camera width/height must be positive");
 	if (cam->samplesPerPixel < 0) return fail(WBRT_ERR_INVALID, "samplesPerPixel must be >= 0");
-	if ((size_t)bsx * (size_t)bsy > ctx->n_seeds)
+	if (check_seeds && (size_t)bsx * (size_t)bsy > ctx->n_seeds)
 		return fail(WBRT_ERR_INVALID, "seed buffer smaller than one block (wbrt_upload_seeds)");
 	if ((long long)cam->width * cam->height > (1LL << 30) || cam->width > (1 << 23) || cam->height > (1 << 23))
 		return fail(WBRT_ERR_INVALID, "image too large");
@@ -239,6 +265,7 @@ int timing_end(wbrt_context *ctx, hipStream_t stream)
 int scheduled_launch(wbrt_context *ctx, const RenderParams &p, hipStream_t stream, const WbrtSchedule *fixed)
 {
 	const bool timing = ctx->timing && !fixed;
+	{ int rc = await_inputs(ctx, stream); if (rc) return rc; }
 	if (timing) { int rc = timing_begin(ctx, stream); if (rc) return rc; }
 	RenderParams q = p;
 	const long long total = (long long)p.bsx * p.bsy * p.nbx * p.nby;
@@ -267,9 +294,8 @@ int scheduled_launch(wbrt_context *ctx, const RenderParams &p, hipStream_t strea
 			if (rc) return rc;
 			s.costs = (int *)ctx->costs.p; s.order = (int *)ctx->order.p;
 			s.tile_costs = (int *)ctx->tile_costs.p; s.hist = (unsigned *)ctx->hist.p;
-			// the arrays are shared by every launch of this context: a launch on another stream waits until
-			// the previous launch has finished with them
-			if (ctx->render_busy) HIP_TRY(hipStreamWaitEvent(stream, ctx->render_done, 0));
+			// (the arrays are shared by every launch of this context: await_inputs above made a launch on another
+			// stream wait until the previous launch has finished with them)
 		}
 		// The full launch records the exact counts of every pixel stream; while the view (camera,
 		// tiling, depth, scene, mesh mode) stays the same they price the next launch, whatever its
@@ -311,6 +337,7 @@ int scheduled_launch(wbrt_context *ctx, const RenderParams &p, hipStream_t strea
 	else HIP_TRY(wbrt_launch_render(q, stream));
 	HIP_TRY(hipEventRecord(ctx->render_done, stream));
 	ctx->render_busy = true;
+	ctx->render_stream = stream;
 	if (timing) return timing_end(ctx, stream);
 	return WBRT_OK;
 }
@@ -342,12 +369,18 @@ int wbrt_create(int device_ordinal, wbrt_context **out)
 	e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
 	if (e != hipSuccess) { delete ctx; return fail(WBRT_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorName(e)); }
 	e = hipEventCreateWithFlags(&ctx->render_done, hipEventDisableTiming);
-	if (e != hipSuccess) { (void)hipStreamDestroy(ctx->stream); delete ctx; return fail(WBRT_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorName(e)); }
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->seeds_ready, hipEventDisableTiming);
+	if (e != hipSuccess)
+	{
+		if (ctx->render_done) (void)hipEventDestroy(ctx->render_done);
+		(void)hipStreamDestroy(ctx->stream); delete ctx;
+		return fail(WBRT_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorName(e));
+	}
 	// this device's copy of the static schedule array (wbrt_render_frame_device_noalloc)
 	e = wbrt_scratch_init(device_ordinal);
 	if (e != hipSuccess)
 	{
-		(void)hipEventDestroy(ctx->render_done); (void)hipStreamDestroy(ctx->stream); delete ctx;
+		(void)hipEventDestroy(ctx->render_done); (void)hipEventDestroy(ctx->seeds_ready); (void)hipStreamDestroy(ctx->stream); delete ctx;
 		return fail(WBRT_ERR_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorName(e));
 	}
 	*out = ctx;
@@ -361,6 +394,7 @@ int wbrt_destroy(wbrt_context *ctx)
 	(void)hipDeviceSynchronize();
 	for (auto &ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
 	if (ctx->render_done) (void)hipEventDestroy(ctx->render_done);
+	if (ctx->seeds_ready) (void)hipEventDestroy(ctx->seeds_ready);
 	DevBuf *all[] = { &ctx->sph_geom, &ctx->sph_radius, &ctx->sph_mat_a, &ctx->sph_mat_b, &ctx->tri_geom,
 	                  &ctx->tri_shade, &ctx->mat_table, &ctx->tri_orig, &ctx->box_min, &ctx->box_max,
 	                  &ctx->box_range, &ctx->bvh_nodes[0], &ctx->bvh_tris[0], &ctx->bvh_roots[0],
@@ -665,11 +699,12 @@ int wbrt_make_seeds_device(wbrt_context *ctx, uint64_t base_seed, uint32_t shard
 		rc = ctx->seeds.reserve(n * sizeof(uint32_t));
 		if (rc) return rc;
 	}
-	// a launch of this context on ANOTHER stream may still read the buffer
-	if (ctx->render_busy) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, ctx->render_done, 0));
+	// a launch of this context on ANOTHER stream may still read the buffer, or an earlier generation still write it
+	rc = await_inputs(ctx, (hipStream_t)stream);
+	if (rc) return rc;
 	HIP_TRY(wbrt_launch_make_seeds(wbrt_seed_stream_state_(base_seed, shard), (uint32_t *)ctx->seeds.p, n, (hipStream_t)stream));
 	ctx->n_seeds = n;
-	return WBRT_OK;
+	return seeds_generated(ctx, (hipStream_t)stream);
 }
 
 int wbrt_render_shards(wbrt_context *ctx, const wbrt_camera *camera, int32_t num_shards, const int32_t *shard_spp, uint64_t base_seed,
@@ -683,6 +718,12 @@ int wbrt_render_shards(wbrt_context *ctx, const wbrt_camera *camera, int32_t num
 		return fail(WBRT_ERR_INVALID, "bad camera");
 	const size_t bytes = (size_t)camera->width * camera->height * 3 * sizeof(float);
 	const size_t block_px = (size_t)(int)camera->blockSize.x * (size_t)(int)camera->blockSize.y;
+	{
+		// an invalid camera or a context without scene or sky leaves the caller's image as it was
+		RenderParams check;
+		rc = make_params(ctx, camera, true, check, false);
+		if (rc) return rc;
+	}
 	HIP_TRY(hipMemsetAsync(device_image, 0, bytes, (hipStream_t)stream));
 	// This rank's shards in ONE launch where possible (a lane renders its pixel's stream of every shard in turn and adds
 	// each sum to the pixel: the same sums in the same order as the launches below, without their start-up and drain):
@@ -716,11 +757,14 @@ int wbrt_render_shards(wbrt_context *ctx, const wbrt_camera *camera, int32_t num
 				rc = ctx->seeds.reserve(all * sizeof(uint32_t));
 				if (rc) return rc;
 			}
-			if (ctx->render_busy) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, ctx->render_done, 0));
+			rc = await_inputs(ctx, (hipStream_t)stream);
+			if (rc) return rc;
 			for (int k = 0; k < n; ++k)
 				HIP_TRY(wbrt_launch_make_seeds(wbrt_seed_stream_state_(base_seed, (uint32_t)mine[(size_t)k]),
 				                               (uint32_t *)ctx->seeds.p + (size_t)k * block_px, block_px, (hipStream_t)stream));
 			ctx->n_seeds = all;
+			rc = seeds_generated(ctx, (hipStream_t)stream);
+			if (rc) return rc;
 			wbrt_camera c = *camera;
 			c.samplesPerPixel = first_spp;
 			RenderParams p;
@@ -842,7 +886,8 @@ int wbrt_render_sharded_frame(wbrt_comm *comm, wbrt_context *const *ctxs, int32_
 	}
 	if (n > 1)
 	{
-		int rc = wbrt_comm_allreduce_sum(comm, images.data(), count, streams.data());
+		// only GPU 0's buffer is read back: a reduce to it moves half of what an all-reduce moves
+		int rc = wbrt_comm_reduce_sum(comm, images.data(), count, 0, streams.data());
 		if (rc) return rc;
 	}
 	int rc = bind(ctxs[0]);
@@ -887,6 +932,8 @@ int wbrt_primary_ids_frame(wbrt_context *ctx, const wbrt_camera *camera, int32_t
 	rc = ctx->ids.reserve(bytes);
 	if (rc) return rc;
 	p.ids = (int *)ctx->ids.p;
+	rc = await_inputs(ctx, ctx->stream);
+	if (rc) return rc;
 	HIP_TRY(wbrt_launch_ids(p, ctx->stream));
 	HIP_TRY(hipMemcpyAsync(host_ids, p.ids, bytes, hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -903,6 +950,8 @@ int wbrt_count_events_frame(wbrt_context *ctx, const wbrt_camera *camera, uint64
 	if (rc) return rc;
 	size_t bytes = WBRT_NUM_COUNTERS * sizeof(unsigned long long);
 	rc = ctx->counters.reserve(bytes);
+	if (rc) return rc;
+	rc = await_inputs(ctx, ctx->stream);
 	if (rc) return rc;
 	HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, bytes, ctx->stream));
 	p.counters = (unsigned long long *)ctx->counters.p;
@@ -1025,6 +1074,16 @@ int wbrt_tune_(wbrt_context *ctx, const char *key, int value)
 	return WBRT_OK;
 }
 
+// Test hook (not in the public header): bytes currently allocated for one of the context's schedule buffers.
+long long wbrt_buffer_bytes_(wbrt_context *ctx, const char *name)
+{
+	if (!ctx || !name) return -1;
+	const std::string k(name);
+	const DevBuf *b = k == "costs" ? &ctx->costs : k == "tile_costs" ? &ctx->tile_costs : k == "order" ? &ctx->order : k == "hist" ? &ctx->hist : nullptr;
+	if (!b) return -1;
+	return b->p ? (long long)b->bytes : 0;
+}
+
 // Test hook (not in the public header): loop iterations (ray segments) each pixel took.
 int wbrt_pixel_costs_(wbrt_context *ctx, const wbrt_camera *camera, int32_t *host_costs)
 {
@@ -1042,6 +1101,8 @@ int wbrt_pixel_costs_(wbrt_context *ctx, const wbrt_camera *camera, int32_t *hos
 	HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, bytes, ctx->stream));
 	p.counters = (unsigned long long *)ctx->counters.p;
 	p.costs = (int *)ctx->ids.p;
+	rc = await_inputs(ctx, ctx->stream);
+	if (rc) return rc;
 	HIP_TRY(wbrt_launch_render(p, ctx->stream));
 	HIP_TRY(hipMemcpyAsync(host_costs, p.costs, cbytes, hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(hipStreamSynchronize(ctx->stream));

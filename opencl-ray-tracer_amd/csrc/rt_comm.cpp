@@ -35,6 +35,7 @@ struct Rccl
 	result_t (*CommInitAll)(comm_t *, int, const int *) = nullptr;
 	result_t (*CommDestroy)(comm_t) = nullptr;
 	result_t (*AllReduce)(const void *, void *, size_t, int, int, comm_t, hipStream_t) = nullptr;
+	result_t (*Reduce)(const void *, void *, size_t, int, int, int, comm_t, hipStream_t) = nullptr;
 	result_t (*GroupStart)() = nullptr;
 	result_t (*GroupEnd)() = nullptr;
 	const char *(*GetErrorString)(result_t) = nullptr;
@@ -42,32 +43,45 @@ struct Rccl
 Rccl g_rccl;
 std::mutex g_rccl_mutex;
 
-bool load_rccl(std::string &why)
+// Loads the library from the first of `names` that opens and resolves the entry points into r.
+bool load_rccl_from(const char *const *names, int n_names, Rccl &r, std::string &why)
 {
-	std::lock_guard<std::mutex> lock(g_rccl_mutex);
-	if (g_rccl.handle) return true;
-	const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
 	void *h = nullptr;
-	for (const char *n : names)
+	std::string last;
+	for (int i = 0; i < n_names && !h; ++i)
 	{
-		h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-		if (h) break;
+		h = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+		if (!h)
+		{
+			const char *e = dlerror(); // one call: it clears the message it returns
+			last = e ? e : "dlopen failed";
+		}
 	}
-	if (!h) { why = std::string("RCCL not found: ") + (dlerror() ? dlerror() : "dlopen failed"); return false; }
-	Rccl r;
+	if (!h) { why = "RCCL not found: " + last; return false; }
 	r.CommInitAll = (decltype(r.CommInitAll))dlsym(h, "ncclCommInitAll");
 	r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
 	r.AllReduce = (decltype(r.AllReduce))dlsym(h, "ncclAllReduce");
+	r.Reduce = (decltype(r.Reduce))dlsym(h, "ncclReduce");
 	r.GroupStart = (decltype(r.GroupStart))dlsym(h, "ncclGroupStart");
 	r.GroupEnd = (decltype(r.GroupEnd))dlsym(h, "ncclGroupEnd");
 	r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
-	if (!r.CommInitAll || !r.CommDestroy || !r.AllReduce || !r.GroupStart || !r.GroupEnd)
+	if (!r.CommInitAll || !r.CommDestroy || !r.AllReduce || !r.Reduce || !r.GroupStart || !r.GroupEnd)
 	{
 		why = "RCCL library lacks a required symbol";
 		dlclose(h);
 		return false;
 	}
 	r.handle = h;
+	return true;
+}
+
+bool load_rccl(std::string &why)
+{
+	std::lock_guard<std::mutex> lock(g_rccl_mutex);
+	if (g_rccl.handle) return true;
+	const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+	Rccl r;
+	if (!load_rccl_from(names, 3, r, why)) return false;
 	g_rccl = r;
 	return true;
 }
@@ -130,6 +144,38 @@ int wbrt_comm_destroy(wbrt_comm *comm)
 }
 
 int32_t wbrt_comm_size(const wbrt_comm *comm) { return comm ? (int32_t)comm->devices.size() : 0; }
+
+// Test hook (not in the public header): what wbrt_comm_create does when RCCL cannot be loaded, with the library name
+// given by the caller (a name that does not exist forces the failure).  Never replaces a library already in use.
+int wbrt_rccl_probe_(const char *library_name)
+{
+	if (!library_name) return fail(WBRT_ERR_INVALID, "null library name");
+	Rccl r;
+	std::string why;
+	if (!load_rccl_from(&library_name, 1, r, why)) return fail(WBRT_ERR_NO_DEVICE, why);
+	return WBRT_OK; // the handle stays open: a loaded RCCL is never unloaded
+}
+
+int wbrt_comm_reduce_sum(wbrt_comm *comm, void *const *device_buffers, size_t count, int32_t root, void *const *streams)
+{
+	if (!comm || !device_buffers) return fail(WBRT_ERR_INVALID, "null argument");
+	const size_t n = comm->devices.size();
+	if (root < 0 || (size_t)root >= n) return fail(WBRT_ERR_INVALID, "root out of range");
+	for (size_t i = 0; i < n; ++i)
+		if (!device_buffers[i]) return fail(WBRT_ERR_INVALID, "null device buffer");
+	if (n == 1) return WBRT_OK;
+	result_t rc = g_rccl.GroupStart();
+	if (rc != 0) return fail(WBRT_ERR_HIP, rccl_error("ncclGroupStart", rc));
+	for (size_t i = 0; i < n; ++i)
+	{
+		rc = g_rccl.Reduce(device_buffers[i], device_buffers[i], count, /*ncclFloat32*/ 7, /*ncclSum*/ 0, root, comm->comms[i],
+		                   streams ? (hipStream_t)streams[i] : nullptr);
+		if (rc != 0) { (void)g_rccl.GroupEnd(); return fail(WBRT_ERR_HIP, rccl_error("ncclReduce", rc)); }
+	}
+	rc = g_rccl.GroupEnd();
+	if (rc != 0) return fail(WBRT_ERR_HIP, rccl_error("ncclGroupEnd", rc));
+	return WBRT_OK;
+}
 
 int wbrt_comm_allreduce_sum(wbrt_comm *comm, void *const *device_buffers, size_t count, void *const *streams)
 {

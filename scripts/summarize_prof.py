@@ -49,6 +49,32 @@ for d in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write", "pmc_tcp"):
             print("    %-28s %18.3f  (SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU), largest dispatch)" % (
                 "active lanes per VALU inst", max(ctrs["SQ_THREAD_CYCLES_VALU"]) / (64.0 * max(ctrs["SQ_ACTIVE_INST_VALU"]))))
 
+# Derived utilisation of the largest dispatch of every render kernel (the full launch).  SIMDs = 256 CUs x 4; a wave64 VALU
+# instruction occupies its SIMD's issue port for 2 cycles on gfx950 (32 lanes per clock), so
+#   VALU issue %  = 2 x SQ_INSTS_VALU       / (SIMDs x cycles)   instructions issued against the 2-cycle ceiling
+#   VALUBusy %    = 2 x SQ_ACTIVE_INST_VALU / (SIMDs x cycles)   the same from the busy counter (includes multi-pass instructions)
+#   VALU lanes %  = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)   active lanes per issued instruction
+#   wait %        = SQ_WAIT_ANY / SQ_WAVE_CYCLES                  share of resident wave-cycles spent waiting
+# cycles = GRBM_GUI_ACTIVE / 8 (the counter sums the 8 XCDs) of the same kernel's largest dispatch in the sq2 pass.
+sq, sq2 = pmc("pmc_sq"), pmc("pmc_sq2")
+SIMDS, MEASURED_RATE = 1024.0, 0.87e9  # measured plain-VALU issue rate per SIMD under load (scripts/ubench/valu_rate.hip), instructions/s
+rows = []
+for k, c in sq.items():
+    if "k_render" not in k or k not in sq2 or "GRBM_GUI_ACTIVE" not in sq2[k] or "SQ_INSTS_VALU" not in c:
+        continue
+    cycles = max(sq2[k]["GRBM_GUI_ACTIVE"]) / 8.0
+    insts, busy = max(c["SQ_INSTS_VALU"]), max(c.get("SQ_ACTIVE_INST_VALU", [0.0]))
+    lanes = max(c["SQ_THREAD_CYCLES_VALU"]) / (64.0 * busy) if busy else float("nan")
+    wait = max(c["SQ_WAIT_ANY"]) / max(c["SQ_WAVE_CYCLES"]) if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c else float("nan")
+    rows.append((k, cycles, 200.0 * insts / (SIMDS * cycles), 200.0 * busy / (SIMDS * cycles), 100.0 * lanes, 100.0 * wait,
+                 100.0 * insts / (SIMDS * MEASURED_RATE * cycles / 2.4e9)))
+if rows:
+    print("== derived utilisation, largest dispatch per kernel")
+    for k, cycles, issue, busy, lanes, wait, vs_measured in rows:
+        print("  %s" % k[:100])
+        print("    cycles %.4g (%.3f ms at 2.4 GHz)  VALU issue %.1f %%  VALUBusy %.1f %%  active lanes %.1f %%  waiting %.1f %% of wave-cycles  "
+              "(issue rate = %.0f %% of the measured 0.87 G inst/s/SIMD plain-VALU rate)" % (cycles, cycles / 2.4e6, issue, busy, lanes, wait, vs_measured))
+
 # HBM bytes of one full render launch for bench.py's roofline.traffic: WRITE_SIZE + 2 x FETCH_SIZE of the largest
 # dispatch (both counters are in KB; gfx950 tallies wide reads at half their bytes, so the doubled figure is an upper bound)
 if len(sys.argv) > 2:
@@ -57,7 +83,7 @@ if len(sys.argv) > 2:
     write = max((max(v["WRITE_SIZE"]) for k, v in pmc("pmc_write").items() if "k_render<false" in k), default=None)
     if fetch is not None and write is not None:
         entry = {"bytes_per_launch": (write + 2.0 * fetch) * 1024.0, "fetch_kb": fetch, "write_kb": write,
-                 "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, largest k_render<false,...> dispatch: WRITE_SIZE + 2 x FETCH_SIZE (profiles/r2, %s)" % os.path.basename(out)}
+                 "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, largest k_render<false,...> dispatch: WRITE_SIZE + 2 x FETCH_SIZE (profiles/r3, %s)" % os.path.basename(out)}
         path = os.path.join(out, "traffic_%s.json" % sys.argv[2])
         json.dump({sys.argv[2]: entry}, open(path, "w"), indent=1)
         print("== wrote %s: %.1f MB per launch" % (path, entry["bytes_per_launch"] / 1e6))

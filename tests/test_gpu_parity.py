@@ -544,6 +544,68 @@ def test_launches_of_one_context_on_two_streams_are_ordered(gpu_ctx):
         gpu_ctx.set_schedule_reuse(True)
 
 
+@pytest.mark.parametrize("entry", ["small_frame", "noalloc"])
+def test_unscheduled_and_noalloc_launches_on_two_streams_are_ordered(gpu_ctx, entry):
+    """The same ordering for the launch paths that take no schedule arrays from the context: a frame too small for the
+    longest-first schedule, and the entry point that allocates nothing.  Each launch's seeds are generated on the
+    launch's own stream while the previous launch (other stream) may still be reading the buffer."""
+    import torch
+    scene = pkg.scene_readme()
+    cam = pkg.camera_readme(200, 96, 50) if entry == "small_frame" else pkg.camera_readme(384, 32, 50)
+    bw, bh = pkg.set_blocks(cam, 1 if entry == "small_frame" else 4)
+    gpu_ctx.upload_scene(scene)
+    want = []
+    for v in range(4):
+        gpu_ctx.upload_seeds(pkg.make_seeds(bw * bh, 56, shard=v))
+        want.append(gpu_ctx.render_frame(cam, pkg.OUT_SUM))
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    bufs = [torch.zeros(cam.height * cam.width * 3, dtype=torch.float32, device="cuda:0") for _ in range(4)]
+    torch.cuda.synchronize()
+    render = gpu_ctx.render_frame_device if entry == "small_frame" else gpu_ctx.render_frame_device_noalloc
+    for v in range(4):  # no host synchronisation between the launches
+        st = streams[v % 2].cuda_stream
+        gpu_ctx.make_seeds_device(bw * bh, 56, v, stream=st)
+        render(cam, bufs[v].data_ptr(), pkg.OUT_SUM, stream=st)
+    # an upload right behind them must wait for ALL of them, not only the last
+    gpu_ctx.upload_seeds(np.zeros(bw * bh, dtype=np.uint32))
+    torch.cuda.synchronize()
+    for v in range(4):
+        assert np.array_equal(bits(bufs[v].cpu().numpy().reshape(want[v].shape)), bits(want[v])), v
+
+
+def test_seed_generation_on_another_stream_orders_the_render(gpu_ctx):
+    """wbrt_make_seeds_device on a caller's stream, then a render on the context's own stream: the render waits for the
+    generation (event recorded behind it).  A long filler ahead of the generation on its stream makes sure the render
+    would otherwise start first and read the zeros uploaded before."""
+    import torch
+    scene, cam = pkg.scene_readme(), pkg.camera_readme(200, 3, 50)
+    bw, bh = pkg.set_blocks(cam, 1)
+    gpu_ctx.upload_scene(scene)
+    gpu_ctx.upload_seeds(pkg.make_seeds(bw * bh, 0x1234, shard=3))
+    want = gpu_ctx.render_frame(cam)
+    want_ids = gpu_ctx.primary_ids(cam)
+    want_counts = gpu_ctx.count_events(cam)
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device="cuda:0")
+    torch.cuda.synchronize()
+    for call in ("render", "ids", "counters"):
+        gpu_ctx.upload_seeds(np.zeros(bw * bh, dtype=np.uint32))
+        with torch.cuda.stream(side):
+            b = a
+            for _ in range(40):  # tens of milliseconds of work ahead of the seed kernel
+                b = b @ a
+                b = b / b.abs().max()
+        gpu_ctx.make_seeds_device(bw * bh, 0x1234, 3, stream=side.cuda_stream)
+        assert not side.query()  # the filler is still running: the launch below is enqueued before the seeds exist
+        if call == "render":
+            assert np.array_equal(bits(gpu_ctx.render_frame(cam)), bits(want))
+        elif call == "ids":
+            assert np.array_equal(gpu_ctx.primary_ids(cam), want_ids)
+        else:
+            assert gpu_ctx.count_events(cam) == want_counts
+        torch.cuda.synchronize()
+
+
 def test_tonemap_device_equals_host(gpu_ctx):
     import torch
     scene, cam = pkg.scene_readme(), pkg.camera_readme(160, 4, 50)

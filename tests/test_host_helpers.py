@@ -301,6 +301,23 @@ def test_shard_helpers_through_the_c_abi():
             pkg.Comm([0])
 
 
+def test_rccl_load_failure_is_a_clean_error():
+    """The path wbrt_comm_create takes when RCCL cannot be loaded: WBRT_ERR_NO_DEVICE and a message that names the
+    loader's reason (no crash on the loader's cleared error string)."""
+    with pytest.raises(pkg.WbrtError) as e:
+        pkg.rccl_probe("/nonexistent/dir/librccl_absent.so")
+    assert e.value.code == pkg.ERR_NO_DEVICE
+    assert "RCCL not found" in str(e.value) and "librccl_absent" in str(e.value)
+    # twice in a row: the second failure reports its own reason too
+    with pytest.raises(pkg.WbrtError) as e:
+        pkg.rccl_probe("/nonexistent/dir/librccl_absent2.so")
+    assert "librccl_absent2" in str(e.value)
+    # a library that opens but is not RCCL
+    with pytest.raises(pkg.WbrtError) as e:
+        pkg.rccl_probe("libm.so.6")
+    assert "lacks a required symbol" in str(e.value)
+
+
 def test_box_splitter_preserves_order_and_the_picture():
     """wbrt_split_mesh_boxes: contiguous runs, ids ascending with the array, every triangle inside its (padded) box; the
     split scene gives the oracle (the reference's loops) the same image and primary ids as the one-box scene."""

@@ -45,6 +45,37 @@ def test_noalloc_entry_equals_allocating_entry_twice_in_a_row():
         ctx.close()
 
 
+def test_noalloc_entry_leaves_the_context_schedule_buffers_unallocated():
+    """A context that only ever used the entry point that allocates nothing owns no schedule arrays afterwards (a
+    hipMalloc/hipFree pair inside the call would not show in the free-memory figure); also on a side stream with
+    kernel timing switched on, which the entry point ignores."""
+    import torch
+    ctx = pkg.Context(0)
+    try:
+        cam = pkg.camera_readme(640, 24, 50)
+        bw, bh = pkg.set_blocks(cam, 4)
+        ctx.upload_scene(pkg.scene_readme())
+        ctx.upload_seeds(pkg.make_seeds(bw * bh, 44))
+        n = cam.height * cam.width * 3
+        got = torch.zeros(n, dtype=torch.float32, device="cuda:0")
+        side = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        ctx.set_timing(True)
+        ctx.render_frame_device_noalloc(cam, got.data_ptr(), stream=side.cuda_stream)
+        ctx.synchronize()
+        assert ctx.get_timing() == (0.0, 0)  # no events of the context were touched
+        ctx.set_timing(False)
+        for name in ("costs", "tile_costs", "order", "hist"):
+            assert ctx.buffer_bytes(name) == 0, name
+        want = torch.zeros(n, dtype=torch.float32, device="cuda:0")
+        ctx.render_frame_device(cam, want.data_ptr())
+        ctx.synchronize()
+        assert ctx.buffer_bytes("costs") > 0  # the allocating entry point is the one that grows them
+        assert np.array_equal(bits(got.cpu().numpy()), bits(want.cpu().numpy()))
+    finally:
+        ctx.close()
+
+
 def test_noalloc_entry_rejects_frames_beyond_its_static_array():
     import torch
     ctx = pkg.Context(0)
