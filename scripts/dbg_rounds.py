@@ -1,22 +1,25 @@
-"""Scratch (needs the instrumented variant library): wave-rounds and lane-rounds of the two phases of the mesh walk on the stress scene."""
+"""Scratch (needs an instrumented variant library, WBRT_LIB): wave-rounds and lane-rounds of the cooperative walk on
+the f1_car scene and the stress scene.  usage: WBRT_LIB=... python scripts/dbg_rounds.py"""
 import os, sys, ctypes as C
-os.environ["WBRT_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "opencl-ray-tracer_amd", "variants", "libdbg.so")
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
-from util import pkg
+from util import pkg, scene_main_cpp_with_mesh
 import numpy as np
-scene = pkg.scene_stress(500, 224, 224, 16, 16)
-cam = pkg.camera_stress(1920, 8, 50)
-bw, bh = pkg.set_blocks(cam, 4)
-ctx = pkg.Context(0); ctx.upload_scene(scene); ctx.upload_seeds(pkg.make_seeds(bw * bh, 11))
-ctx.tune("lpt", 0)
-out = (C.c_ulonglong * 4)()
-for mode, name in ((pkg.MESH_BVH, "proven"), (pkg.MESH_BVH_CAPPED, "capped")):
-    ctx.set_mesh_mode(mode)
-    ctx.render_frame(cam)
-    pkg.lib().wbrt_dbg_rounds_(out, 1)
-    ctx.set_timing(True); ctx.render_frame(cam); ms, n = ctx.get_timing(); ctx.set_timing(False)
-    pkg.lib().wbrt_dbg_rounds_(out, 1)
-    a_w, a_l, b_w, b_l = [int(x) for x in out]
-    print("%s: %.1f ms; box-tree phase: %d wave-rounds, %.1f%% lanes busy; cooperative phase: %d wave-rounds, %.1f%% lanes busy" % (
-        name, ms, a_w, 100.0 * a_l / max(a_w * 64, 1), b_w, 100.0 * b_l / max(b_w * 64, 1)), flush=True)
-ctx.close()
+out = (C.c_ulonglong * 8)()
+for sname in ("f1_car", "stress"):
+    if sname == "stress":
+        scene, cam = pkg.scene_stress(500, 224, 224, 16, 16), pkg.camera_stress(1920, 8, 50)
+    else:
+        scene, cam = scene_main_cpp_with_mesh("f1_car"), pkg.camera_main_cpp(1920, 8, 50)
+    bw, bh = pkg.set_blocks(cam, 4)
+    ctx = pkg.Context(0); ctx.upload_scene(scene); ctx.upload_seeds(pkg.make_seeds(bw * bh, 11))
+    ctx.tune("lpt", 0)
+    for mode, name in ((pkg.MESH_BVH, "proven"), (pkg.MESH_BVH_CAPPED, "capped")):
+        ctx.set_mesh_mode(mode)
+        ctx.render_frame(cam)
+        pkg.lib().wbrt_dbg_rounds_(out, 1)
+        ctx.set_timing(True); ctx.render_frame(cam); ms, n = ctx.get_timing(); ctx.set_timing(False)
+        pkg.lib().wbrt_dbg_rounds_(out, 1)
+        r, busy, inner, leaf, rin = [int(x) for x in out[:5]]
+        print("%s %s: %.1f ms; %.2f M wave-rounds (%.2f M with inner nodes), lanes busy %.1f%%; lane visits: inner %.1f M, leaf slots %.1f M" % (
+            sname, name, ms, r / 1e6, rin / 1e6, 100.0 * busy / max(r * 64, 1), inner / 1e6, leaf / 1e6), flush=True)
+    ctx.close()
