@@ -443,7 +443,7 @@ void wbrt_build_bvh(const float4 *tri_geom, const int2 *ranges, int B, bool spli
 			MarginBuilder mbld;
 			mbld.prims = std::move(prims);
 			mbld.out = &bvh;
-			mbld.depth_limit = WBRT_BVH_DEPTH2;
+			mbld.depth_limit = WBRT_BVH_STACK;
 			Bounds all;
 			all.reset();
 			for (const Prim &p : mbld.prims) for (int a = 0; a < 3; ++a) if (p.b.mn[a] > -DBL_MAX / 2 && p.b.mx[a] < DBL_MAX / 2) { all.mn[a] = std::min(all.mn[a], p.b.mn[a]); all.mx[a] = std::max(all.mx[a], p.b.mx[a]); }
@@ -463,7 +463,7 @@ void wbrt_build_bvh(const float4 *tri_geom, const int2 *ranges, int B, bool spli
 		Builder bl;
 		bl.prims = std::move(prims);
 		bl.out = &bvh;
-		bl.depth_limit = WBRT_BVH_DEPTH2;
+		bl.depth_limit = WBRT_BVH_STACK;
 		bl.split_by_e = split_by_e;
 		Bounds rb;
 		double re;
@@ -478,204 +478,6 @@ void wbrt_build_bvh(const float4 *tri_geom, const int2 *ranges, int B, bool spli
 		bvh.mbox.assign(bvh.nodes.size() * 12, 0.0f);
 		for (size_t n = 0; n < bvh.nodes.size(); ++n)
 			for (int k = 0; k < 12; ++k) bvh.mbox[12 * n + k] = (k % 6) < 3 ? -1.0f : 1.0f;
-	}
-}
-
-// ------------------------------------------------------------------ 4-wide form
-// The kernel's walk is a chain of dependent node fetches, one per round, so it visits the trees two binary levels at a
-// time: a 4-wide node holds the boxes of up to four descendants of a binary node.  Every box of the 4-wide tree is a box
-// of the binary tree, with the same E and m-box, so what the margins prove for the binary tree holds unchanged.
-// Which descendants: the children, then repeatedly the inner child with the largest surface area is replaced by its own two
-// children until four slots are used (a large child is the one a ray most likely enters anyway).  The kernel's stack
-// bounds the depth of the 4-wide tree (WBRT_BVH_DEPTH4): a child whose subtree could not be finished within the levels
-// left — ceil(height / 2) levels always suffice — is opened first, whatever its area.
-namespace {
-
-struct Collapse
-{
-	WbrtBvh &bvh;
-	std::vector<int> height; // binary levels below each binary node (a node over two leaves: 1)
-	int max_depth4 = 0;
-	bool ok = true;
-
-	int height_of(int ref) const { return ref < 0 ? 0 : height[(size_t)ref]; }
-
-	int compute_height(int node)
-	{
-		const WbrtBvhNode &n = bvh.nodes[(size_t)node];
-		const int hl = n.left >= 0 ? compute_height(n.left) : 0, hr = n.right >= 0 ? compute_height(n.right) : 0;
-		return height[(size_t)node] = 1 + std::max(hl, hr);
-	}
-
-	struct Child { int ref; float mn[3], mx[3], e; float mb[6]; };
-
-	void children_of(int node, Child out[2]) const
-	{
-		const WbrtBvhNode &n = bvh.nodes[(size_t)node];
-		const float *m = &bvh.mbox[12 * (size_t)node];
-		for (int a = 0; a < 3; ++a)
-		{
-			out[0].mn[a] = n.lmin[a]; out[0].mx[a] = n.lmax[a];
-			out[1].mn[a] = n.rmin[a]; out[1].mx[a] = n.rmax[a];
-		}
-		out[0].ref = n.left; out[1].ref = n.right;
-		out[0].e = n.le; out[1].e = n.re;
-		for (int k = 0; k < 6; ++k) { out[0].mb[k] = m[k]; out[1].mb[k] = m[6 + k]; }
-	}
-
-	static double area(const Child &c)
-	{
-		const double x = (double)c.mx[0] - c.mn[0], y = (double)c.mx[1] - c.mn[1], z = (double)c.mx[2] - c.mn[2];
-		const double a = x * y + y * z + z * x;
-		return a == a ? a : DBL_MAX; // unbounded boxes first
-	}
-
-	// levels: 4-wide levels available for the subtree of `node`, this node included
-	int collapse(int node, int depth4, int levels)
-	{
-		if (levels < 1 || (height[(size_t)node] + 1) / 2 > levels) { ok = false; return 0; }
-		max_depth4 = std::max(max_depth4, depth4 + 1);
-		Child ch[4];
-		int n = 2;
-		children_of(node, ch);
-		for (;;)
-		{
-			if (n == 4) break;
-			int pick = -1;
-			// a child that would not fit below this node must be opened; else the largest inner child
-			for (int i = 0; i < n; ++i)
-				if (ch[i].ref >= 0 && (height_of(ch[i].ref) + 1) / 2 > levels - 1) { pick = i; break; }
-			if (pick < 0)
-				for (int i = 0; i < n; ++i)
-					if (ch[i].ref >= 0 && (pick < 0 || area(ch[i]) > area(ch[pick]))) pick = i;
-			if (pick < 0) break;
-			Child two[2];
-			children_of(ch[pick].ref, two);
-			ch[pick] = two[0];
-			ch[n++] = two[1];
-		}
-		// (only the node's two children can be too high, and both get opened then: 2 -> 3 -> 4 slots; their children, and
-		// the children of a child opened by choice, fit: ceil((h - 2) / 2) = ceil(h / 2) - 1)
-		for (int i = 0; i < n; ++i)
-			if (ch[i].ref >= 0 && (height_of(ch[i].ref) + 1) / 2 > levels - 1) ok = false;
-		const size_t self = bvh.nodes4.size();
-		bvh.nodes4.emplace_back();
-		WbrtBvhNode4 out;
-		for (int i = 0; i < 4; ++i)
-		{
-			if (i < n)
-			{
-				for (int a = 0; a < 3; ++a) { out.mn[i][a] = ch[i].mn[a]; out.mx[i][a] = ch[i].mx[a]; }
-				out.e[i] = ch[i].e;
-				for (int k = 0; k < 6; ++k) out.mbox[i][k] = ch[i].mb[k];
-				out.ref[i] = ch[i].ref >= 0 ? collapse(ch[i].ref, depth4 + 1, levels - 1) : ch[i].ref;
-			}
-			else
-			{
-				for (int a = 0; a < 3; ++a) { out.mn[i][a] = INFINITY; out.mx[i][a] = -INFINITY; }
-				out.e[i] = 0.0f;
-				for (int k = 0; k < 6; ++k) out.mbox[i][k] = k < 3 ? -1.0f : 1.0f;
-				out.ref[i] = WBRT_BVH_NONE;
-			}
-		}
-		bvh.nodes4[self] = out;
-		return (int)self;
-	}
-};
-
-} // namespace
-
-bool wbrt_collapse4(WbrtBvh &bvh)
-{
-	bvh.nodes4.clear();
-	bvh.depth4 = 0;
-	Collapse c{ bvh };
-	c.height.assign(bvh.nodes.size(), 0);
-	for (WbrtBvhRoot &r : bvh.roots)
-	{
-		r.ref4 = r.ref;
-		if (r.empty || r.ref < 0) continue; // no triangles, or a single leaf
-		c.compute_height(r.ref);
-		if (c.height[(size_t)r.ref] > WBRT_BVH_DEPTH2) return false;
-		// one level more than the shallowest possible form: room for the choice by area without spending the stack entries
-		// that scenes with many boxes use for queued boxes
-		r.ref4 = c.collapse(r.ref, 0, std::min(WBRT_BVH_DEPTH4, (c.height[(size_t)r.ref] + 1) / 2 + 1));
-		if (!c.ok) return false;
-	}
-	bvh.depth4 = c.max_depth4;
-	return true;
-}
-
-// Device record of a 4-wide node (layout: rt_device.h).  Per axis the children's planes are stored as bytes q: plane =
-// origin + q * scale with scale a power of two (the product is exact in float), origin the smallest lower plane of the
-// children; lower planes are rounded down and upper planes up in exact arithmetic, so the decoded box contains the child's
-// box.  Planes that are not finite (triangles with NaN or infinite vertices keep an unbounded box so that they stay
-// reachable) are stored as -+2^125: the walk's margin arithmetic overflows on such a box and visits it for every ray.
-void wbrt_pack_node4(const WbrtBvhNode4 &n, uint32_t *w)
-{
-	auto bits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
-	const double huge = std::ldexp(1.0, 125);
-	for (int k = 0; k < WBRT_NODE4_WORDS; ++k) w[k] = 0;
-	for (int a = 0; a < 3; ++a)
-	{
-		double mn[4], mx[4], lo = DBL_MAX, hi = -DBL_MAX;
-		for (int c = 0; c < 4; ++c)
-		{
-			if (n.ref[c] == WBRT_BVH_NONE) continue;
-			mn[c] = (double)n.mn[c][a]; mx[c] = (double)n.mx[c][a];
-			if (!(mn[c] <= mx[c])) { mn[c] = -huge; mx[c] = huge; } // NaN or inverted: unbounded
-			mn[c] = std::max(mn[c], -huge); mx[c] = std::min(mx[c], huge);
-			if (mn[c] > mx[c]) { mn[c] = -huge; mx[c] = huge; }       // a box beyond +-2^125
-			lo = std::min(lo, mn[c]); hi = std::max(hi, mx[c]);
-		}
-		float origin = 0.0f;
-		int e = -120;
-		if (lo <= hi)
-		{
-			origin = (float)lo; // exact: one of the float planes, or -2^125
-			while (std::ldexp(255.0, e) < hi - lo) ++e; // hi - lo <= 2^126: e <= 119
-		}
-		const double scale = std::ldexp(1.0, e);
-		w[a] = bits(origin);
-		w[3 + a] = bits((float)scale);
-		for (int c = 0; c < 4; ++c)
-		{
-			uint32_t ql = 255u, qh = 0u; // unused slot: an inverted box
-			if (n.ref[c] != WBRT_BVH_NONE)
-			{
-				double l = std::floor((mn[c] - origin) / scale), h = std::ceil((mx[c] - origin) / scale);
-				while (l > 0.0 && (double)origin + l * scale > mn[c]) l -= 1.0;
-				while (h < 255.0 && (double)origin + h * scale < mx[c]) h += 1.0;
-				ql = (uint32_t)std::min(std::max(l, 0.0), 255.0);
-				qh = (uint32_t)std::min(std::max(h, 0.0), 255.0);
-			}
-			w[6 + a] |= ql << (8 * c);
-			w[9 + a] |= qh << (8 * c);
-		}
-	}
-	for (int c = 0; c < 4; ++c)
-	{
-		w[12 + c] = (uint32_t)n.ref[c];
-		// E as the upper half of a float, rounded up (NaN and +inf keep their class)
-		uint32_t e = bits(n.e[c]);
-		uint32_t half = e >> 16;
-		if ((e & 0xFFFFu) && (e & 0x7F800000u) != 0x7F800000u) half += 1u;
-		if (n.e[c] != n.e[c]) half = 0x7FC0u;
-		w[16 + c / 2] |= (half & 0xFFFFu) << (16 * (c & 1));
-		// m-box components as bytes, rounded outwards: lower bounds down, upper bounds up (b -> b/127 - 1)
-		for (int k = 0; k < 6; ++k)
-		{
-			const bool up = k >= 3;
-			const float v = n.mbox[c][k];
-			const double x = ((double)v + 1.0) * 127.0;
-			double b = up ? std::ceil(x) : std::floor(x);
-			if (up && b / 127.0 - 1.0 < (double)v) b += 1.0;
-			if (!up && b / 127.0 - 1.0 > (double)v) b -= 1.0;
-			if (!(b >= 0.0)) b = 0.0;
-			if (!(b <= 254.0)) b = 254.0;
-			if (!(v == v)) b = up ? 254.0 : 0.0; // NaN: the widest box
-			w[18 + k] |= (uint32_t)b << (8 * c);
-		}
 	}
 }
 
@@ -706,7 +508,7 @@ void wbrt_append_sphere_tree(const float4 *sph_geom, const float *radius, int S,
 	Builder bl;
 	bl.prims = std::move(prims);
 	bl.out = &bvh;
-	bl.depth_limit = WBRT_BVH_DEPTH2;
+	bl.depth_limit = WBRT_BVH_STACK;
 	bl.split_by_e = true; // a few huge spheres (a ground sphere) must not widen every box
 	Bounds rb;
 	double re;
@@ -743,24 +545,6 @@ extern "C" int wbrt_bvh_build_(const float *tri_geom, const int *ranges, int B, 
 	}
 	if (depth_out) *depth_out = bvh.depth;
 	return (int)bvh.nodes.size();
-}
-
-
-// Test hook (not in the public header): the 4-wide device records of the same build (WBRT_NODE4_WORDS words per node),
-// the leaf slots, per box the 4-wide root reference (WBRT_BVH_NONE: no triangles) and the depth of the 4-wide trees.
-// Returns the node count, -(needed) - 1 when a capacity is too small, INT_MIN when the trees cannot be collapsed.
-extern "C" int wbrt_bvh_build4_(const float *tri_geom, const int *ranges, int B, uint32_t *words_out, int nodes_cap,
-                                int *tri_index_out, int tri_cap, int *roots_out, int *depth4_out, int split_by_e)
-{
-	WbrtBvh bvh;
-	wbrt_build_bvh(reinterpret_cast<const float4 *>(tri_geom), reinterpret_cast<const int2 *>(ranges), B, split_by_e != 0, bvh);
-	if (!wbrt_collapse4(bvh)) return (int)0x80000000;
-	if ((int)bvh.nodes4.size() > nodes_cap || (int)bvh.tri_index.size() > tri_cap) return -(int)bvh.nodes4.size() - 1;
-	for (size_t n = 0; n < bvh.nodes4.size(); ++n) wbrt_pack_node4(bvh.nodes4[n], words_out + WBRT_NODE4_WORDS * n);
-	if (!bvh.tri_index.empty()) std::memcpy(tri_index_out, bvh.tri_index.data(), bvh.tri_index.size() * sizeof(int));
-	for (int b = 0; b < B; ++b) roots_out[b] = bvh.roots[(size_t)b].empty ? WBRT_BVH_NONE : bvh.roots[(size_t)b].ref4;
-	if (depth4_out) *depth4_out = bvh.depth4;
-	return (int)bvh.nodes4.size();
 }
 
 

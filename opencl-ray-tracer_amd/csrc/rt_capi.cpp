@@ -83,6 +83,7 @@ struct wbrt_context
 	int top_depth = 0;            // 0: no such hierarchy
 	int box_tree_min = 48;        // measured crossover between 36 and 64 boxes
 	DevBuf bvh_nodes[2], bvh_tris[2], bvh_roots[2], bvh_pairs[2]; // [0] plain surface-area trees (capped margins), [1] built for the proven margins
+	DevBuf bvh_mbox;              // m-boxes of the nodes of variant [1]
 	const float4 *bvh_ptr[2][3] = {};
 	int bvh_depth[2] = {0, 0};
 	int mesh_mode = WBRT_MESH_BVH;
@@ -212,13 +213,12 @@ int make_params(wbrt_context *ctx, const wbrt_camera *cam, bool whole_frame, Ren
 	if (walks_hierarchies(ctx))
 	{
 		const int variant = ctx->mesh_mode == WBRT_MESH_BVH ? 1 : 0;
-		p.sc.bvh_nodes = (const uint4 *)ctx->bvh_ptr[variant][0];
+		p.sc.bvh_nodes = ctx->bvh_ptr[variant][0];
 		p.sc.bvh_tris = ctx->bvh_ptr[variant][1];
 		p.sc.bvh_roots = ctx->bvh_ptr[variant][2];
 		p.sc.bvh_pairs = (const float4 *)ctx->bvh_pairs[variant].p;
-		p.sc.bvh_has_mbox = variant == 1 ? 1 : 0;
-		// a visit of a 4-wide node pushes up to three siblings: a root-to-leaf path needs 3 entries per level
-		p.sc.bvh_box_slots = WBRT_BVH_STACK - 3 * ctx->bvh_depth[variant] + 1;
+		p.sc.bvh_mbox = variant == 1 ? (const uint4 *)ctx->bvh_mbox.p : nullptr;
+		p.sc.bvh_box_slots = WBRT_BVH_STACK - ctx->bvh_depth[variant] + 1;
 		if (ctx->top_depth > 0)
 		{
 			// the walk over the boxes uses the top of each lane's stack while hit boxes are queued at its bottom
@@ -398,7 +398,7 @@ int wbrt_destroy(wbrt_context *ctx)
 	DevBuf *all[] = { &ctx->sph_geom, &ctx->sph_radius, &ctx->sph_mat_a, &ctx->sph_mat_b, &ctx->tri_geom,
 	                  &ctx->tri_shade, &ctx->mat_table, &ctx->tri_orig, &ctx->box_min, &ctx->box_max,
 	                  &ctx->box_range, &ctx->bvh_nodes[0], &ctx->bvh_tris[0], &ctx->bvh_roots[0],
-	                  &ctx->bvh_nodes[1], &ctx->bvh_tris[1], &ctx->bvh_roots[1], &ctx->bvh_pairs[0], &ctx->bvh_pairs[1], &ctx->top_nodes, &ctx->top_box, &ctx->sky, &ctx->seeds, &ctx->image, &ctx->ids, &ctx->counters, &ctx->rgb8,
+	                  &ctx->bvh_nodes[1], &ctx->bvh_tris[1], &ctx->bvh_roots[1], &ctx->bvh_pairs[0], &ctx->bvh_pairs[1], &ctx->bvh_mbox, &ctx->top_nodes, &ctx->top_box, &ctx->sky, &ctx->seeds, &ctx->image, &ctx->ids, &ctx->counters, &ctx->rgb8,
 	                  &ctx->costs, &ctx->tile_costs, &ctx->order, &ctx->hist };
 	for (DevBuf *b : all) b->release();
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -530,16 +530,13 @@ int wbrt_upload_scene(wbrt_context *ctx, const wbrt_sphere *spheres, int32_t S,
 	}
 	ctx->sc.sph_moderate = spheres_moderate ? 1 : 0;
 	// hierarchies (render build only; the counting and primary-id builds keep the loops)
-	bool trees_ok = true;
-	for (int variant = 0; variant < 2 && (Tg > 0 || sphere_tree) && trees_ok; ++variant)
+	for (int variant = 0; variant < 2 && (Tg > 0 || sphere_tree); ++variant)
 	{
 		WbrtBvh bvh;
 		wbrt_build_bvh(tgeom.data(), brange.data(), B, variant == 1, bvh);
 		const size_t tri_slots = bvh.tri_index.size();
 		if (sphere_tree) wbrt_append_sphere_tree(geom.data(), radius.data(), S, bvh);
-		// the kernel walks the 4-wide form; trees too deep for its stack (more than 4 * 2^16 triangles in one box) leave the
-		// scene to the loops
-		if (!wbrt_collapse4(bvh)) { trees_ok = false; break; }
+		static_assert(sizeof(WbrtBvhNode) == 4 * sizeof(float4), "node layout");
 		// Triangle leaves are stored as PAIRS (the kernel tests two triangles per round with packed arithmetic), 5 float4 each:
 		// p0.x p0.x' p0.y p0.y' | p0.z p0.z' e0.x e0.x' | e0.y e0.y' e0.z e0.z' | e1.x e1.x' e1.y e1.y' | e1.z e1.z' pos pos'
 		// (pos = position in the grouped order; pos' = -1: no second triangle, its numbers repeat the first).  A leaf
@@ -564,13 +561,20 @@ int wbrt_upload_scene(wbrt_context *ctx, const wbrt_sphere *spheres, int32_t S,
 			}
 			return ~((base << 4) | (pairs - 1));
 		};
-		for (WbrtBvhNode4 &b : bvh.nodes4)
-			for (int c = 0; c < 4; ++c) if (b.ref[c] != WBRT_BVH_NONE) b.ref[c] = leaf_as_pairs(b.ref[c]);
-		for (WbrtBvhRoot &r : bvh.roots) if (!r.empty) r.ref4 = leaf_as_pairs(r.ref4);
+		for (WbrtBvhNode &b : bvh.nodes) { b.left = leaf_as_pairs(b.left); b.right = leaf_as_pairs(b.right); }
+		for (WbrtBvhRoot &r : bvh.roots) if (!r.empty) r.ref = leaf_as_pairs(r.ref);
 		if (bpairs.empty()) bpairs.resize(5, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
-		std::vector<uint32_t> bnodes(std::max<size_t>(bvh.nodes4.size(), 1) * WBRT_NODE4_WORDS, 0u);
-		std::vector<float4> btris(bvh.tri_index.size() * 3), broots(bvh.roots.size() * 2);
-		for (size_t n = 0; n < bvh.nodes4.size(); ++n) wbrt_pack_node4(bvh.nodes4[n], &bnodes[WBRT_NODE4_WORDS * n]);
+		std::vector<float4> bnodes(bvh.nodes.size() * 4), btris(bvh.tri_index.size() * 3), broots(bvh.roots.size() * 2);
+		for (size_t n = 0; n < bvh.nodes.size(); ++n) // children interleaved: the kernel handles them as packed pairs
+		{
+			const WbrtBvhNode &b = bvh.nodes[n];
+			float left, right;
+			std::memcpy(&left, &b.left, 4); std::memcpy(&right, &b.right, 4);
+			bnodes[4 * n + 0] = make_float4(b.lmin[0], b.rmin[0], b.lmin[1], b.rmin[1]);
+			bnodes[4 * n + 1] = make_float4(b.lmin[2], b.rmin[2], b.lmax[0], b.rmax[0]);
+			bnodes[4 * n + 2] = make_float4(b.lmax[1], b.rmax[1], b.lmax[2], b.rmax[2]);
+			bnodes[4 * n + 3] = make_float4(left, right, b.le, b.re);
+		}
 		for (size_t k = 0; k < bvh.tri_index.size(); ++k)
 		{
 			const size_t src = (size_t)bvh.tri_index[k];
@@ -589,23 +593,48 @@ int wbrt_upload_scene(wbrt_context *ctx, const wbrt_sphere *spheres, int32_t S,
 		for (size_t b = 0; b < bvh.roots.size(); ++b)
 		{
 			const WbrtBvhRoot &r = bvh.roots[b];
-			float ref; std::memcpy(&ref, &r.ref4, 4);
+			float ref; std::memcpy(&ref, &r.ref, 4);
 			broots[2 * b] = make_float4(r.mn[0], r.mn[1], r.mn[2], ref);
 			broots[2 * b + 1] = make_float4(r.mx[0], r.mx[1], r.mx[2], r.empty ? -1.0f : r.e);
 		}
 		UP(bvh_nodes[variant], bnodes); UP(bvh_tris[variant], btris); UP(bvh_roots[variant], broots); UP(bvh_pairs[variant], bpairs);
+		if (variant == 1)
+		{
+			// m-box components as bytes, rounded outwards: lower bounds down, upper bounds up (b -> b/127 - 1)
+			auto pack = [](const float *v, bool up) {
+				unsigned w = 0;
+				for (int a = 0; a < 3; ++a)
+				{
+					const double x = ((double)v[a] + 1.0) * 127.0;
+					double b = up ? std::ceil(x) : std::floor(x);
+					if (up && b / 127.0 - 1.0 < (double)v[a]) b += 1.0;
+					if (!up && b / 127.0 - 1.0 > (double)v[a]) b -= 1.0;
+					if (!(b >= 0.0)) b = 0.0;        // also NaN: the widest box
+					if (!(b <= 254.0)) b = 254.0;
+					if (!(v[a] == v[a])) b = up ? 254.0 : 0.0;
+					w |= (unsigned)b << (8 * a);
+				}
+				return w;
+			};
+			std::vector<uint4> mb(bvh.nodes.size());
+			for (size_t n = 0; n < bvh.nodes.size(); ++n)
+			{
+				const float *m = &bvh.mbox[12 * n];
+				mb[n] = make_uint4(pack(m, false), pack(m + 3, true), pack(m + 6, false), pack(m + 9, true));
+			}
+			UP(bvh_mbox, mb);
+		}
 		ctx->bvh_ptr[variant][0] = (const float4 *)ctx->bvh_nodes[variant].p;
 		ctx->bvh_ptr[variant][1] = (const float4 *)ctx->bvh_tris[variant].p;
 		ctx->bvh_ptr[variant][2] = (const float4 *)ctx->bvh_roots[variant].p;
-		ctx->bvh_depth[variant] = bvh.depth4;
+		ctx->bvh_depth[variant] = bvh.depth;
 	}
-	ctx->have_bvh = (Tg > 0 || sphere_tree) && trees_ok;
-	ctx->have_sphere_tree = sphere_tree && trees_ok;
+	ctx->have_bvh = Tg > 0 || sphere_tree;
+	ctx->have_sphere_tree = sphere_tree;
 #undef UP
 	SceneDev &sc = ctx->sc;
-	sc.bvh_nodes = nullptr; // chosen per render (make_params)
-	sc.bvh_tris = sc.bvh_roots = nullptr;
-	sc.bvh_has_mbox = 0;
+	sc.bvh_nodes = sc.bvh_tris = sc.bvh_roots = nullptr; // chosen per render (make_params)
+	sc.bvh_mbox = nullptr;
 	sc.bvh_pairs = nullptr;
 	sc.bvh_rho = 0.0f;
 	sc.sph_tree = 0;

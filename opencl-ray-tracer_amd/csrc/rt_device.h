@@ -46,14 +46,15 @@ struct SceneDev
 	const int2   *box_range;  // [B] first, last+1 into the grouped triangle arrays
 	int B;
 	// triangle hierarchies, one per bounding box (absent: bvh_nodes == nullptr)
-	const uint4 *bvh_nodes;   // 6 per node (96 bytes): FOUR children, their boxes as 8-bit offsets from the node's own origin
-	                          // (rounded outwards), see WBRT_NODE4_* below
+	const float4 *bvh_nodes;  // 4 per node, children interleaved: lmin.x rmin.x lmin.y rmin.y | lmin.z rmin.z lmax.x rmax.x |
+	                          // lmax.y rmax.y lmax.z rmax.z | left right E_left E_right
 	const float4 *bvh_tris;   // 3 per leaf slot of the sphere hierarchy: center.xyz r^2 | - | - index - -
 	const float4 *bvh_pairs;  // 5 per pair slot of a triangle leaf, two triangles interleaved:
 	                          // p0.x p0.x' p0.y p0.y' | p0.z p0.z' e0.x e0.x' | e0.y e0.y' e0.z e0.z' | e1.x e1.x' e1.y e1.y' | e1.z e1.z' pos pos'
 	                          // (pos: position in the grouped order as int bits; pos' = -1: no second triangle)
 	const float4 *bvh_roots;  // 2 per box: min.xyz ref | max.xyz E   (E < 0: box without triangles)
-	int bvh_has_mbox;         // 1: the nodes carry E and m-boxes of their children (trees built for the proven margins)
+	const uint4  *bvh_mbox;   // 1 per node (proven-margin trees only): bytes 0-2 of x|y|z|w = left lo, left hi, right lo, right hi of the
+	                          // children's m-boxes, m = (e0 x e1)/(|e0||e1|), byte b -> b/127 - 1
 	float bvh_rho;
 	int sph_tree;             // 1: bvh_roots[B] is a hierarchy over the spheres (leaf slot: center.xyz r^2 | - | - index - -)
 	int bvh_box_slots;        // stack entries free for queued boxes: WBRT_BVH_STACK - tree depth + 1
@@ -103,40 +104,17 @@ struct RenderParams
 // Binary hierarchy over the triangles of every bounding box.  A child reference >= 0 names a
 // node; < 0 names a leaf: ~ref = (first leaf slot << 4) | (triangles - 1) as built; on the device a triangle leaf counts
 // pair slots instead (see SceneDev::bvh_pairs).
-// The kernel walks the trees in 4-WIDE form (wbrt_collapse4: two binary levels per node, WbrtBvhNode4): a visit pushes up
-// to three siblings, so a stack of WBRT_BVH_STACK entries serves 4-wide trees of depth WBRT_BVH_DEPTH4, which binary trees
-// of depth WBRT_BVH_DEPTH2 always collapse to.
 #define WBRT_BVH_STACK 24
-#define WBRT_BVH_DEPTH4 (WBRT_BVH_STACK / 3)
-#define WBRT_BVH_DEPTH2 (2 * WBRT_BVH_DEPTH4)
-#define WBRT_BVH_NONE ((int)0x80000000) // child slot without a child
 struct WbrtBvhNode
 {
 	float lmin[3], lmax[3], rmin[3], rmax[3];
 	int left, right;
 	float le, re; // max |e0||e1| over the triangles below each child
 };
-// A node of the 4-wide form, before quantisation.  Unused child slots: ref = WBRT_BVH_NONE.
-struct WbrtBvhNode4
-{
-	float mn[4][3], mx[4][3];
-	int ref[4];        // >= 0: a WbrtBvhNode4; < 0: a leaf, as in the binary form
-	float e[4];        // max |e0||e1| below each child
-	float mbox[4][6];  // lo.xyz hi.xyz of each child's m-box ([-1,1]^3 where nothing is known)
-};
-// Device record of a 4-wide node: 24 32-bit words.
-//   0-2 origin.xyz (float)   3-5 scale.xyz (float, powers of two)
-//   6-8 lower planes x,y,z   9-11 upper planes x,y,z: one byte per child (child c in byte c): plane = origin + byte * scale,
-//       lower planes rounded down, upper planes rounded up, so the decoded box contains the child's box
-//   12-15 child references
-//   16-17 E of the children as the upper halves of floats, rounded up (children 0,1 | 2,3; low half = even child)
-//   18-23 m-box planes lo.x lo.y lo.z hi.x hi.y hi.z, one byte per child, byte b -> b/127 - 1, rounded outwards
-#define WBRT_NODE4_WORDS 24
 struct WbrtBvhRoot
 {
 	float mn[3], mx[3], e;
 	int ref, empty;
-	int ref4;          // the root's reference in the 4-wide form
 };
 struct WbrtBvh
 {
@@ -147,15 +125,7 @@ struct WbrtBvh
 	// child, each vector flipped into the child's own hemisphere; [-1,1]^3 where nothing is known
 	std::vector<float> mbox;
 	int depth = 0;
-	// 4-wide form of the same trees (wbrt_collapse4)
-	std::vector<WbrtBvhNode4> nodes4;
-	int depth4 = 0;    // largest number of 4-wide nodes on a path from a root to a leaf
 };
-// Fills bvh.nodes4 / roots[].ref4 / depth4 from the binary trees.  Returns false when a tree is deeper than WBRT_BVH_DEPTH2
-// (it cannot be walked with the kernel's stack).
-bool wbrt_collapse4(WbrtBvh &bvh);
-// Device record (WBRT_NODE4_WORDS words) of one 4-wide node.
-void wbrt_pack_node4(const WbrtBvhNode4 &n, uint32_t *words);
 void wbrt_build_bvh(const float4 *tri_geom, const int2 *ranges, int B, bool split_by_e, WbrtBvh &bvh);
 bool wbrt_build_box_tree(const float4 *box_min, const float4 *box_max, const int2 *ranges, int B,
                          std::vector<float4> &nodes, std::vector<int> &box_of_rank, int &depth);

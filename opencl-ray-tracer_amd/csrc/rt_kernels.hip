@@ -361,3 +361,13 @@ hipError_t wbrt_launch_math_probe(int op, const float *a, const float *b, float 
 	hipLaunchKernelGGL(k_math_probe, dim3((n + 255) / 256), dim3(256), 0, stream, op, a, b, out, n);
 	return hipGetLastError();
 }
+
+#ifdef WBRT_WALK_STATS
+// Instrumented build only: reads (and clears) the walk counters of rt_render.inc.
+extern "C" void wbrt_dbg_rounds_(unsigned long long *out, int reset)
+{
+	(void)hipDeviceSynchronize();
+	(void)hipMemcpyFromSymbol(out, HIP_SYMBOL(strict_impl::g_walk_stats), 8 * sizeof(unsigned long long));
+	if (reset) { unsigned long long z[8] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(strict_impl::g_walk_stats), z, sizeof z); }
+}
+#endif

@@ -1,5 +1,5 @@
 """Scratch (needs an instrumented variant library, WBRT_LIB): wave-rounds and lane-rounds of the cooperative walk on
-the f1_car scene and the stress scene.  usage: WBRT_LIB=... python scripts/dbg_rounds.py"""
+the f1_car scene and the stress scene.  build: make -C opencl-ray-tracer_amd/csrc ../variants/walk_stats.so; usage: WBRT_LIB=$PWD/opencl-ray-tracer_amd/variants/walk_stats.so python scripts/dbg_rounds.py"""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from util import pkg, scene_main_cpp_with_mesh

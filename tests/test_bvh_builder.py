@@ -9,7 +9,6 @@ import pytest
 from util import pkg, golden, triangles_from_soup
 
 STACK = 24  # WBRT_BVH_STACK in csrc/rt_device.h
-DEPTH2 = 16  # WBRT_BVH_DEPTH2: binary depth limit of the builders (two binary levels per 4-wide node)
 
 
 def _build(geom, ranges, split_by_e=0):
@@ -36,7 +35,7 @@ def _geom_from_soup(soup):
 
 
 def _check_tree(geom, ranges, nodes, tri_index, roots, depth):
-    assert depth <= DEPTH2
+    assert depth <= STACK
     p0 = geom[:, 0:3].astype(np.float64)
     verts = np.stack([p0, p0 + geom[:, 3:6], p0 + geom[:, 6:9]], axis=1)  # [T,3,3]
     e = np.linalg.norm(geom[:, 3:6].astype(np.float64), axis=1) * np.linalg.norm(geom[:, 6:9].astype(np.float64), axis=1)
@@ -75,86 +74,6 @@ def _check_tree(geom, ranges, nodes, tri_index, roots, depth):
     assert (seen[inside] == 1).all() and (seen[~inside] == 0).all()
 
 
-def _build4(geom, ranges, split_by_e=0):
-    L = pkg.lib()
-    L.wbrt_bvh_build4_.restype = C.c_int
-    T, B = geom.shape[0], ranges.shape[0]
-    words = np.zeros((max(2 * T, 1), 24), np.uint32)
-    tri_index = np.zeros(max(T, 1), np.int32)
-    roots = np.zeros(B, np.int32)
-    depth4 = C.c_int(0)
-    p = lambda a: a.ctypes.data_as(C.c_void_p)
-    n = L.wbrt_bvh_build4_(p(geom), p(ranges), B, p(words), words.shape[0], p(tri_index), tri_index.shape[0], p(roots), C.byref(depth4), split_by_e)
-    assert n >= 0
-    return words[:n], tri_index, roots, depth4.value
-
-
-NONE = -(1 << 31)
-
-
-def _check_tree4(geom, ranges, words, tri_index, roots, depth4, bnodes, binary_e):
-    """The 4-wide device records: every triangle of a box in exactly one leaf below the box's root; every DECODED child box
-    (origin + byte * scale, evaluated exactly) contains the triangles below the child; the decoded E bounds |e0||e1| from
-    above and lies within 1 % of a binary node's E; depth within what the kernel's stack serves (3 entries per level)."""
-    assert 3 * depth4 <= STACK
-    p0 = geom[:, 0:3].astype(np.float64)
-    verts = np.stack([p0, p0 + geom[:, 3:6], p0 + geom[:, 6:9]], axis=1)
-    e = np.linalg.norm(geom[:, 3:6].astype(np.float64), axis=1) * np.linalg.norm(geom[:, 6:9].astype(np.float64), axis=1)
-    seen = np.zeros(geom.shape[0], np.int32)
-    levels = [0]
-
-    def walk(ref, level):
-        levels[0] = max(levels[0], level)
-        if ref < 0:
-            leaf = ~ref
-            first, count = leaf >> 4, (leaf & 15) + 1
-            idx = tri_index[first:first + count]
-            seen[idx] += 1
-            return idx
-        w = words[ref]
-        origin = w[0:3].view(np.float32).astype(np.float64)
-        scale = w[3:6].view(np.float32).astype(np.float64)
-        refs = w[12:16].view(np.int32)
-        got = []
-        for c in range(4):
-            if refs[c] == NONE:
-                for a in range(3):  # an unused slot decodes to an inverted box
-                    assert (w[6 + a] >> (8 * c)) & 255 > (w[9 + a] >> (8 * c)) & 255
-                continue
-            below = walk(int(refs[c]), level + 1)
-            got.append(below)
-            finite = np.isfinite(verts[below]).all(axis=(1, 2))
-            for a in range(3):
-                lo = origin[a] + float((w[6 + a] >> (8 * c)) & 255) * scale[a]
-                hi = origin[a] + float((w[9 + a] >> (8 * c)) & 255) * scale[a]
-                assert (verts[below][finite][:, :, a] >= lo).all() and (verts[below][finite][:, :, a] <= hi).all()
-                if np.isposinf(verts[below][:, :, a]).any():  # an infinite coordinate below: the axis reaches 2^125
-                    assert hi >= 2.0 ** 124
-                if np.isneginf(verts[below][:, :, a]).any():
-                    assert lo <= -2.0 ** 124
-            half = (int(w[16 + c // 2]) >> (16 * (c & 1))) & 0xFFFF
-            ec = np.array([half << 16], np.uint32).view(np.float32)[0]
-            fin = np.isfinite(e[below])
-            assert (e[below][fin] <= ec).all()
-            if np.isfinite(ec) and ec > 0 and binary_e.size:
-                assert np.min(np.abs(binary_e / np.float64(ec) - 1.0)) < 0.01  # some binary node's E, rounded up by < 2^-7
-        return np.concatenate(got)
-
-    for b, (first, last) in enumerate(ranges):
-        if last <= first:
-            assert roots[b] == NONE
-            continue
-        got = walk(int(roots[b]), 0)
-        assert sorted(got.tolist()) == list(range(first, last))
-    assert levels[0] == depth4
-    inside = np.zeros(geom.shape[0], bool)
-    for first, last in ranges:
-        inside[first:last] = True
-    assert (seen[inside] == 1).all() and (seen[~inside] == 0).all()
-    # two binary levels per node: at most one 4-wide node per binary node, usually about half as many
-    assert len(words) <= max(len(bnodes), 1)
-
-
 @pytest.mark.parametrize("mesh", ["f1_car", "burger", "random", "coincident", "line", "tiny"])
 def test_builder_invariants(mesh):
     rs = np.random.RandomState(5)
@@ -179,9 +98,6 @@ def test_builder_invariants(mesh):
     for split_by_e in (0, 1):
         nodes, tri_index, roots, depth = _build(geom, ranges, split_by_e)
         _check_tree(geom, ranges, nodes, tri_index, roots, depth)
-        words, tri_index4, roots4, depth4 = _build4(geom, ranges, split_by_e)
-        _check_tree4(geom, ranges, words, tri_index4, roots4, depth4, nodes, nodes[:, 14:16].astype(np.float64).ravel())
-        print(mesh, split_by_e, "binary nodes", len(nodes), "depth", depth, "-> 4-wide nodes", len(words), "depth", depth4)
 
 
 def test_builder_handles_non_finite_vertices():
@@ -193,13 +109,8 @@ def test_builder_handles_non_finite_vertices():
     geom = _geom_from_soup(soup)
     ranges = np.array([[0, 200]], np.int32)
     nodes, tri_index, roots, depth = _build(geom, ranges)
-    assert depth <= DEPTH2
+    assert depth <= STACK
     assert sorted(tri_index[:200].tolist()) == list(range(200))
-    # the 4-wide records: non-finite planes are stored as -+2^125 (a box the walk enters for every ray), every triangle stays reachable
-    for split_by_e in (0, 1):
-        words, tri_index4, roots4, depth4 = _build4(geom, ranges, split_by_e)
-        _check_tree4(geom, ranges, words, tri_index4, roots4, depth4, nodes, np.zeros(0))
-        assert (words[int(roots4[0]), 3:6].view(np.float32) >= 2.0 ** 100).any()
 
 
 def _box_tree(mn, mx, ranges):
