@@ -104,6 +104,7 @@ struct wbrt_context
 	unsigned long long scene_generation = 0;
 	SceneDev sc{};
 	bool have_scene = false, have_sky = false, have_bvh = false, have_sphere_tree = false;
+	bool mesh_in_range = true; // every finite triangle coordinate lies below 2^40: no product of the reference's triangle test can overflow
 	int sphere_tree_min = 48;  // sphere count from which the render build walks a sphere hierarchy
 	size_t n_seeds = 0;
 	bool timing = false;
@@ -164,7 +165,9 @@ bool walks_hierarchies(const wbrt_context *ctx)
 {
 	// strict margins on a small mesh widen every box to the whole mesh: the cooperative loop is faster there
 	const bool strict_small = ctx->mesh_mode == WBRT_MESH_BVH && ctx->sc.T <= ctx->strict_loop_max && !ctx->have_sphere_tree;
-	return ctx->mesh_mode != WBRT_MESH_LOOP && ctx->have_bvh && !strict_small;
+	// (meshes with coordinates beyond 2^40 keep the loops: the margins of the walk assume that the reference's float
+	// arithmetic, gpu_kernel.cl:489-520, does not overflow)
+	return ctx->mesh_mode != WBRT_MESH_LOOP && ctx->have_bvh && !strict_small && ctx->mesh_in_range;
 }
 
 // Fills launch parameters from the camera; validates what the kernels assume.
@@ -417,6 +420,7 @@ int wbrt_upload_scene(wbrt_context *ctx, const wbrt_sphere *spheres, int32_t S,
 	if (rc) return rc;
 	// until every buffer of the new scene is in place the context has no scene (a failed upload leaves it so)
 	ctx->have_scene = ctx->have_bvh = ctx->have_sphere_tree = false;
+	ctx->mesh_in_range = true;
 	ctx->top_depth = 0;
 	ctx->recorded_spp = 0;
 
@@ -484,6 +488,8 @@ int wbrt_upload_scene(wbrt_context *ctx, const wbrt_sphere *spheres, int32_t S,
 		float mi; std::memcpy(&mi, &found->second, 4);
 		tshade[k] = make_float4(ux, uy, uz, mi);
 		torig[k] = j;
+		const float coords[9] = { t.p0.x, t.p0.y, t.p0.z, t.p1.x, t.p1.y, t.p1.z, t.p2.x, t.p2.y, t.p2.z };
+		for (float c : coords) if (std::isfinite(c) && std::fabs(c) >= 0x1p40f) ctx->mesh_in_range = false;
 	}
 	std::vector<float4> bmin((size_t)B), bmax((size_t)B);
 	std::vector<int2> brange((size_t)B);

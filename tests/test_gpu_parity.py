@@ -871,6 +871,108 @@ def test_random_mesh_scenes(gpu_ctx, seed):
     assert np.array_equal(gpu_ctx.primary_ids(cam), O.primary_ids(cam, seeds))
 
 
+def _mesh_only_scene(soup, scale, translate):
+    mat = pkg.material((0.8, 0.6, 0.2), 0.5, 0.0, pkg.METAL)
+    tris, mn, mx = triangles_from_soup(soup, (scale, scale, scale), translate, mat, 0)
+    boxes = (pkg.BoundingBox * 1)()
+    boxes[0] = pkg.BoundingBox(0, pkg.vec3(*mn), pkg.vec3(*mx))
+    verts = np.frombuffer(tris, dtype=np.float32).reshape(-1, 16)[:, :9].reshape(-1, 3, 3).astype(np.float64)
+    return pkg.Scene(triangles=tris, boxes=boxes), verts
+
+
+def _three_modes(ctx, cam):
+    """The frame in the loop, the proven walk (forced on small meshes too) and the capped walk."""
+    out = {}
+    try:
+        ctx.tune("strict_loop_max", 0)
+        for mode in (pkg.MESH_LOOP, pkg.MESH_BVH, pkg.MESH_BVH_CAPPED):
+            ctx.set_mesh_mode(mode)
+            out[mode] = ctx.render_frame(cam)
+    finally:
+        ctx.tune("strict_loop_max", 256)
+        ctx.set_mesh_mode(pkg.MESH_BVH)
+    return out
+
+
+CAPPED_DIFFERENCES = {}  # what the unproven capped walk did on the same frames (reported, not asserted)
+
+
+@pytest.mark.parametrize("mesh", ["f1_car", "burger"])
+def test_proven_walk_where_its_bound_is_tight(gpu_ctx, mesh):
+    """Rays that graze the planes of the LARGEST triangles of a mesh — camera in the plane and 1e-4 to either side of
+    it, looking along the plane — and rays that run along shared edges (camera on an edge's line, looking at the edge's
+    far vertex): the regime where the reference's own accept/reject decision is rounding noise and the determinant
+    bound of the proven margins degenerates to the cutoff bound.  The proven walk must equal the reference's loop bit
+    for bit; the capped walk is run on the same frames and its differences are counted."""
+    soup = golden("meshes.npz")[mesh]
+    scene, verts = _mesh_only_scene(soup, 0.15, (0.0, -0.5, -1.0))
+    gpu_ctx.upload_scene(scene)
+    e0, e1 = verts[:, 1] - verts[:, 0], verts[:, 2] - verts[:, 0]
+    normal = np.cross(e0, e1)
+    area = np.linalg.norm(normal, axis=1)
+    cams = []
+    for t in np.argsort(-area)[:3]:
+        n = normal[t] / area[t]
+        c = verts[t].mean(axis=0)
+        for corner in range(3):
+            start = c + 3.0 * (verts[t, corner] - c)      # in the plane, outside the triangle
+            for off in (0.0, 1e-4, -1e-4):
+                cams.append((start + off * n, c, n, 25.0))
+        a, b = verts[t, 0], verts[t, 1]                    # along an edge of the triangle (shared with its neighbour)
+        cams.append((a - 2.0 * (b - a), b, n, 12.0))
+        cams.append((verts[t, 2] + 1.5 * (verts[t, 2] - c) + 0.3 * n, verts[t, 2], n, 8.0))  # at a vertex, obliquely
+    capped_diff, primary_hits = 0, 0
+    for k, (look_from, look_at, up, fov) in enumerate(cams):
+        focus = float(np.linalg.norm(look_at - look_from))
+        cam = pkg.calculate_camera(tuple(map(float, look_from)), tuple(map(float, look_at)), tuple(map(float, up)), fov, 1.7777777, focus, 0.0,
+                                   128, 72, 2, 6)
+        bw, bh = pkg.set_blocks(cam, 1)
+        gpu_ctx.upload_seeds(pkg.make_seeds(bw * bh, 900 + k))
+        img = _three_modes(gpu_ctx, cam)
+        assert np.array_equal(bits(img[pkg.MESH_BVH]), bits(img[pkg.MESH_LOOP])), (mesh, k)
+        capped_diff += int((bits(img[pkg.MESH_BVH_CAPPED]) != bits(img[pkg.MESH_LOOP])).sum())
+        primary_hits += int((gpu_ctx.primary_ids(cam) >= 0).sum())
+    assert primary_hits > 1000  # the views do look at the mesh
+    CAPPED_DIFFERENCES[mesh] = capped_diff
+    print("capped walk vs loop on %d grazing frames of %s: %d differing floats" % (len(cams), mesh, capped_diff))
+
+
+@pytest.mark.parametrize("scale", [1e-12, 1e-3, 0.3, 1e3, 1e6, 1e13])
+def test_proven_walk_on_scaled_meshes(gpu_ctx, scale):
+    """The burger mesh and its camera scaled together: tiny scales push the reference's products and its determinant towards
+    (and below) its 1e-5 cutoff and into underflow, huge ones towards overflow; scales near 1 put many determinants AT
+    the cutoff.  Whatever the reference's float test then accepts, the proven walk finds the same hits as the loop."""
+    soup = golden("meshes.npz")["burger"]
+    s = float(scale)
+    scene, verts = _mesh_only_scene(soup, 0.15 * s, (0.0, -0.5 * s, -1.0 * s))
+    gpu_ctx.upload_scene(scene)
+    for k, (frm, fov) in enumerate((((0.0, 0.2, 0.6), 60.0), ((0.4, -0.45, -0.2), 40.0), ((0.0, -0.49, -1.0), 100.0))):
+        look_from = tuple(x * s for x in frm)
+        cam = pkg.calculate_camera(look_from, (0.0, -0.4 * s, -1.0 * s), (0.0, 1.0, 0.0), fov, 1.7777777, 1.5 * s, 0.0, 128, 72, 3, 8)
+        bw, bh = pkg.set_blocks(cam, 1)
+        gpu_ctx.upload_seeds(pkg.make_seeds(bw * bh, 950 + k))
+        img = _three_modes(gpu_ctx, cam)
+        assert np.array_equal(bits(img[pkg.MESH_BVH]), bits(img[pkg.MESH_LOOP])), (scale, k)
+        assert np.array_equal(bits(img[pkg.MESH_BVH_CAPPED]), bits(img[pkg.MESH_LOOP])), (scale, k)
+
+
+def test_walk_with_rays_outside_the_range_of_its_margins(gpu_ctx):
+    """Ray origins beyond 2^41 and directions longer than 2^20 (a viewport that far from the camera): outside the range
+    the margins are derived for, such rays visit every node; the result is the loop's."""
+    scene, verts = _mesh_only_scene(golden("meshes.npz")["burger"], 0.15, (0.0, -0.5, -1.0))
+    gpu_ctx.upload_scene(scene)
+    views = [((0.0, 0.0, 6.0e12), 1e-11, 6.0e12),     # far origin, a narrow view of the mesh
+             ((0.0, 0.2, 0.6), 60.0, 4.0e6),          # ordinary origin, direction vectors of length ~4e6
+             ((3.0e12, 2.0e12, 5.0e12), 1e-11, 1.0)]
+    for k, (look_from, fov, focus) in enumerate(views):
+        cam = pkg.calculate_camera(look_from, (0.0, -0.4, -1.0), (0.0, 1.0, 0.0), fov, 1.7777777, focus, 0.0, 128, 72, 3, 8)
+        bw, bh = pkg.set_blocks(cam, 1)
+        gpu_ctx.upload_seeds(pkg.make_seeds(bw * bh, 970 + k))
+        img = _three_modes(gpu_ctx, cam)
+        assert np.array_equal(bits(img[pkg.MESH_BVH]), bits(img[pkg.MESH_LOOP])), k
+        assert np.array_equal(bits(img[pkg.MESH_BVH_CAPPED]), bits(img[pkg.MESH_LOOP])), k
+
+
 @pytest.mark.parametrize("name", ["awkward", "stress36", "many_boxes"])
 def test_box_hierarchy_equals_box_loop(name):
     """The hierarchy over the bounding boxes (used from 48 boxes on, forced here from 2) queues exactly
