@@ -95,6 +95,7 @@ struct wbrt_context
 	float bvh_rho = 2e-4f; // WBRT_MESH_BVH_CAPPED: box margin as a fraction of the ray's distance bound
 	DevBuf sky, seeds, image, ids, counters, rgb8, costs, tile_costs, order, hist;
 	int lpt = 1;        // longest-first scheduling from a pilot pass
+	int lpt_min_stream_spp = 1; // launches whose longest stream has fewer samples go unscheduled (tune key "lpt_min_spp")
 	int pilot_spp = 4;
 	int pilot_depth = 8;          // bounce limit of a pilot launch: its counts only rank tiles, and an unlimited pilot lasts as long as its longest
 	                              // stream (headline cold frame 10.87 ms without a limit, 10.52 / 10.43 / 10.43 ms at 16 / 8 / 5); 0: no limit
@@ -281,10 +282,12 @@ int scheduled_launch(wbrt_context *ctx, const RenderParams &p, hipStream_t strea
 	}
 	// samples per pixel of the whole launch (fused seed shards: all of them)
 	const int launch_spp = p.n_shards > 1 ? p.n_shards * p.spp - (p.n_shards - p.n_full) : p.spp;
+	// samples of the longest stream of the launch: what a schedule can shorten (fused shards run concurrently)
+	const int stream_spp = p.spp;
 	// a pilot takes at most a 24th of the launch's samples: short launches (seed shards) get a shorter pilot.  One 31-spp shard
 	// of the headline frame, cold: 1.66 ms with a 1-spp pilot, 1.72 / 1.74 / 1.78 ms with 2 / 3 / 4 spp, 2.03 ms unscheduled.
 	const int pilot_spp = std::max(1, std::min(ctx->pilot_spp, launch_spp / 24));
-	if (ctx->lpt && total >= 65536 && total % 64 == 0 && launch_spp >= 8)
+	if (ctx->lpt && total >= 65536 && total % 64 == 0 && launch_spp >= 8 && stream_spp >= ctx->lpt_min_stream_spp)
 	{
 		WbrtSchedule s;
 		if (fixed) s = *fixed;
@@ -731,15 +734,19 @@ int wbrt_render_shards(wbrt_context *ctx, const wbrt_camera *camera, int32_t num
 		if (rc) return rc;
 	}
 	HIP_TRY(hipMemsetAsync(device_image, 0, bytes, (hipStream_t)stream));
-	// This rank's shards in ONE launch where possible (a lane renders its pixel's stream of every shard in turn and adds
-	// each sum to the pixel: the same sums in the same order as the launches below, without their start-up and drain):
-	// up to 8 shards whose sample counts are equal or drop by one once (wbrt_split_spp's pattern), at least 1 sample each.
+	// This rank's shards in ONE launch where possible (2, 4, ... 64 adjacent lanes per pixel, one per shard, run the pixel's
+	// streams of all shards concurrently; one lane then adds the sums to the pixel in shard order: the same sums in the same
+	// order as the launches below, and the launch lasts as long as its longest SHARD stream, not the pixel's streams in a row):
+	// 2 to 64 shards whose sample counts are equal or drop by one once (wbrt_split_spp's pattern), at least 1 sample each.
 	{
 		std::vector<int32_t> mine;
 		for (int32_t v = rank; v < num_shards; v += world) mine.push_back(v);
 		const int n = (int)mine.size();
 		// (scenes with a hierarchy over their boxes keep one launch per shard: their render build has no fused form)
-		bool fusable = ctx->fuse_shards && n >= 2 && n <= 8 && !(ctx->top_depth > 0 && walks_hierarchies(ctx));
+		bool fusable = ctx->fuse_shards && n >= 2 && n <= 64 && !(ctx->top_depth > 0 && walks_hierarchies(ctx));
+		int lanes_log2 = 1;
+		while ((1 << lanes_log2) < n) ++lanes_log2;
+		if ((((long long)camera->width * camera->height) << lanes_log2) >= (1LL << 36)) fusable = false; // launch grid limit
 		int first_spp = 0, n_full = n;
 		for (int k = 0; k < n && fusable; ++k)
 		{
@@ -779,6 +786,7 @@ int wbrt_render_shards(wbrt_context *ctx, const wbrt_camera *camera, int32_t num
 			p.out = (float *)device_image;
 			p.out_mode = WBRT_OUT_ACCUMULATE;
 			p.n_shards = n; p.n_full = n_full; p.seeds_stride = (int)block_px;
+			p.shard_lanes_log2 = lanes_log2;
 			return timed_launch(ctx, p, (hipStream_t)stream);
 		}
 	}
@@ -1063,6 +1071,7 @@ int wbrt_tune_(wbrt_context *ctx, const char *key, int value)
 	const std::string k(key);
 	if (k == "lpt") ctx->lpt = value != 0;
 	else if (k == "pilot_spp") ctx->pilot_spp = value > 0 ? value : 4;
+	else if (k == "lpt_min_spp") ctx->lpt_min_stream_spp = value;
 	else if (k == "pilot_depth") ctx->pilot_depth = value;
 	else if (k == "box_tree_min") ctx->box_tree_min = value;
 	else if (k == "sphere_tree_min") ctx->sphere_tree_min = value;

@@ -201,6 +201,7 @@ __global__ void k_cost_scatter(const int *costs, int n, unsigned *offsets, int *
 inline unsigned grid_for(const RenderParams &p, int block)
 {
 	long long total = (long long)p.bsx * p.bsy * p.nbx * p.nby;
+	if (p.n_shards > 1) total <<= p.shard_lanes_log2; // fused seed shards: that many lanes per pixel
 	return (unsigned)((total + block - 1) / block);
 }
 
@@ -287,7 +288,9 @@ hipError_t wbrt_launch_render(const RenderParams &p, hipStream_t stream)
 	if (p.n_shards > 1)
 	{
 		// fused seed shards (accumulating launches of scenes without a hierarchy over the boxes; the caller checks)
-		if (box_tree || p.out_mode != 2 || !p.out || p.costs) return hipErrorInvalidValue;
+		if (box_tree || p.out_mode != 2 || !p.out || p.costs || p.shard_lanes_log2 < 1 || p.shard_lanes_log2 > 6 ||
+		    p.n_shards > (1 << p.shard_lanes_log2)) return hipErrorInvalidValue;
+		if (((long long)p.bsx * p.bsy * p.nbx * p.nby << p.shard_lanes_log2) > 0xFFFFFFFFLL * 64) return hipErrorInvalidValue;
 		if (p.tolerant)
 		{
 			if (mesh) hipLaunchKernelGGL((tolerant_impl::k_render<false, true, false, true>), grid, block, 0, stream, p);

@@ -475,30 +475,31 @@ def test_workgroup_kernel_equals_per_wave_kernel(waves):
                     assert np.array_equal(bits(ctx.render_frame(cam, mode)), bits(ref)), (arith, mode, reuse, "recorded")
 
 
-@pytest.mark.parametrize("name", ["readme", "mesh"])
-def test_fused_seed_shards_equal_one_launch_per_shard(name):
-    """wbrt_render_shards renders a rank's shards in one launch (a lane runs its pixel's stream of every shard in turn);
-    the accumulation buffer must hold exactly what one accumulating launch per shard leaves, for every split of the shards
-    over ranks, with the schedule taken from a pilot and from recorded costs, in both arithmetic modes."""
+@pytest.mark.parametrize("name,shards", [("readme", 8), ("mesh", 8), ("readme", 32), ("mesh", 32)])
+def test_fused_seed_shards_equal_one_launch_per_shard(name, shards):
+    """wbrt_render_shards renders a rank's shards in one launch (adjacent lanes run a pixel's streams of the shards
+    concurrently, one lane adds their sums in shard order); the accumulation buffer must hold exactly what one accumulating
+    launch per shard leaves, for every split of the shards over ranks (2 to 32 shards per rank, also counts that are no
+    power of two), with the schedule taken from a pilot and from recorded costs, in both arithmetic modes."""
     import torch
     if name == "readme":
         scene, cam = pkg.scene_readme(), pkg.camera_readme(384, 0, 50)
     else:
         scene, cam = scene_main_cpp_with_mesh("f1_car"), pkg.camera_main_cpp(384, 0, 50)
     bw, bh = pkg.set_blocks(cam, 4)
-    spp = pkg.split_spp(45, 8)  # 6 6 6 6 6 5 5 5
+    spp = pkg.split_spp(45, 8) if shards == 8 else pkg.split_spp(70, 32)  # 6 6 6 6 6 5 5 5, or 6 shards of 3 and 26 of 2
     cam.samplesPerPixel = max(spp)
     buf = torch.zeros(cam.height * cam.width * 3, dtype=torch.float32, device="cuda:0")
     with pkg.Context(0) as ctx:
         ctx.upload_scene(scene)
         for arith in (pkg.ARITH_STRICT, pkg.ARITH_TOLERANT):
             ctx.set_arith_mode(arith)
-            for world in (1, 2, 3, 8):
-                for rank in range(world):
+            for world in ((1, 2, 3, 8) if shards == 8 else (1, 5, 8)):
+                for rank in range(world if shards == 8 else min(world, 2)):
                     got = {}
                     for fuse in (0, 1, 1):  # the second fused frame is scheduled from the first one's recorded costs
                         ctx.tune("fuse_shards", fuse)
-                        ctx.render_shards(cam, buf.data_ptr(), 8, 77, rank, world, spp)
+                        ctx.render_shards(cam, buf.data_ptr(), shards, 77, rank, world, spp)
                         torch.cuda.synchronize()
                         img = buf.cpu().numpy().copy()
                         if fuse in got:
