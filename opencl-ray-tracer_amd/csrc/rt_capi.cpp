@@ -209,6 +209,12 @@ int make_params(wbrt_context *ctx, const wbrt_camera *cam, bool whole_frame, Ren
 		p.off_bx = (int)cam->blockOffset.x; p.off_by = (int)cam->blockOffset.y;
 		p.out_w = bsx;
 	}
+	{
+		// columns bsx * (block + offset) + in-block column, rows likewise (gpu_kernel.cl:626-627, evaluated in float)
+		const long long c0 = (long long)p.bsx * p.off_bx, c1 = (long long)p.bsx * (p.off_bx + p.nbx);
+		const long long r0 = (long long)p.bsy * p.off_by, r1 = (long long)p.bsy * (p.off_by + p.nby);
+		p.plain_coords = c0 >= 0 && r0 >= 0 && c1 <= (1 << 23) && r1 <= (1 << 23) && cam->width <= (1 << 23) && cam->height <= (1 << 23) ? 1 : 0;
+	}
 	p.seeds = (const uint32_t *)ctx->seeds.p;
 	p.tolerant = ctx->arith_mode == WBRT_ARITH_TOLERANT ? 1 : 0;
 	p.wg = ctx->wg_kernel;

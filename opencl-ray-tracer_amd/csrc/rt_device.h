@@ -77,6 +77,7 @@ struct RenderParams
 	// tiling: blocks of bsx*bsy pixels; this launch covers nbx*nby blocks whose block
 	// indices start at (off_bx, off_by)
 	int bsx, bsy, nbx, nby, off_bx, off_by;
+	int plain_coords;               // 1: every pixel column / row of the launch (block offsets included) lies in [0, 2^23)
 	// output: texel (row, col) relative to the first block lands at out[(row*out_w + col)*3]
 	int out_w;
 	int out_mode;

@@ -374,3 +374,13 @@ extern "C" void wbrt_dbg_rounds_(unsigned long long *out, int reset)
 	if (reset) { unsigned long long z[8] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(strict_impl::g_walk_stats), z, sizeof z); }
 }
 #endif
+
+#ifdef WBRT_PHASE_STATS
+// Instrumented build only: reads (and clears) the phase counters of rt_render.inc.
+extern "C" void wbrt_dbg_phases_(unsigned long long *out, int reset)
+{
+	(void)hipDeviceSynchronize();
+	(void)hipMemcpyFromSymbol(out, HIP_SYMBOL(strict_impl::g_phase), 32 * sizeof(unsigned long long));
+	if (reset) { unsigned long long z[32] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(strict_impl::g_phase), z, sizeof z); }
+}
+#endif

@@ -356,6 +356,20 @@ def test_block_entry_point_equals_frame_region(gpu_ctx):
             assert np.array_equal(bits(blk), bits(frame[by * bh:(by + 1) * bh, bx * bw:(bx + 1) * bw]))
 
 
+def test_block_offsets_outside_the_image(gpu_ctx):
+    """blockOffset is the caller's (main.cpp:234): offsets that put the block left of / below the image or millions of
+    blocks away give negative or huge pixel coordinates, which the reference divides like any other (gpu_kernel.cl:626-627).
+    The block must equal the oracle's for every such offset (the kernel's short division by width / height is only used
+    where the host has checked the coordinates)."""
+    scene, cam = pkg.scene_readme(), pkg.camera_readme(160, 3, 50)
+    seeds = _setup(gpu_ctx, scene, cam, 4, 13)
+    O = orc.Oracle(scene)
+    for off in ((0, 0), (1, 1), (-1, 0), (0, -3), (-2, -2), (200000, 1), (3, 9000000), (-500000, 700000)):
+        c = cam.copy()
+        c.blockOffset = pkg.vec3(off[0], off[1], 0)
+        assert np.array_equal(bits(gpu_ctx.render_block(c)), bits(O.render_block(c, seeds))), off
+
+
 def test_block_callback_delivers_the_reference_order(gpu_ctx):
     scene, cam = pkg.scene_readme(), pkg.camera_readme(160, 4, 50)
     _setup(gpu_ctx, scene, cam, 4, 12)
