@@ -106,7 +106,9 @@ struct RenderParams
 // Binary hierarchy over the triangles of every bounding box.  A child reference >= 0 names a
 // node; < 0 names a leaf: ~ref = (first leaf slot << 4) | (triangles - 1) as built; on the device a triangle leaf counts
 // pair slots instead (see SceneDev::bvh_pairs).
+#ifndef WBRT_BVH_STACK
 #define WBRT_BVH_STACK 24
+#endif
 struct WbrtBvhNode
 {
 	float lmin[3], lmax[3], rmin[3], rmax[3];
