@@ -147,13 +147,17 @@ def other_config_step_ms(pkg, mg, torch, config, steps, device):
 
 
 def profiled_traffic(config):
-    """HBM bytes per launch of the render kernel from the committed PMC summary of this configuration
-    (profiles/r2/traffic.json, condensed from rocprofv3 --pmc passes), or None."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r2", "traffic.json")) as f:
-            return json.load(f).get(config)
-    except (OSError, ValueError):
-        return None
+    """HBM bytes per launch and issue utilisation of the render kernel from the committed PMC summary of this
+    configuration (profiles/r3/traffic.json, else r2; condensed from rocprofv3 --pmc passes), or None."""
+    for rnd in ("r3", "r2"):
+        try:
+            with open(os.path.join(ROOT, "profiles", rnd, "traffic.json")) as f:
+                entry = json.load(f).get(config)
+            if entry:
+                return entry
+        except (OSError, ValueError):
+            pass
+    return None
 
 
 def main():
@@ -440,6 +444,9 @@ def main():
                 "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4),
                 "traffic": None if traffic is None else traffic.get("bytes_per_launch"),
                 "traffic_source": None if traffic is None else traffic.get("source"),
+                # the timed kernel's own issue utilisation from the same profile (VALU issue against the 2-cycle-per-wave64 ceiling,
+                # active lanes per issued instruction, share of wave-cycles spent waiting)
+                "timed_kernel_utilisation": None if traffic is None else traffic.get("utilisation"),
                 "flops_per_launch": flops, "flop_per_path": round(flops / launch_paths, 2),
                 "note": hw_note or ("peak = 256 CUs x 4 SIMDs x 32 lanes x 2 FLOP (FMA) x 2.4 GHz; results are bit-exact with a non-contracting "
                                     "IEEE build, so a counted FLOP issues as a separate mul or add: ceiling 0.5 of peak before divergence"),

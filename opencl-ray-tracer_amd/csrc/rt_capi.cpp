@@ -89,6 +89,7 @@ struct wbrt_context
 	int mesh_mode = WBRT_MESH_BVH;
 	int bvh_steal_min_idle = 8;
 	int fuse_shards = 1;          // wbrt_render_shards renders a rank's shards in one launch where their sample counts allow
+	int shard_lanes_max_pixels = 1 << 20; // ... as concurrent lanes per pixel up to this many pixels, in turn in one lane beyond
 	int wg_kernel = 0, wg_per_cu = 0; // opt-in: waves (4 or 8) of the workgroup render kernel for scenes without meshes, and its workgroups per CU
 	int strict_loop_max = 256;    // proven-margin mode: meshes up to this many triangles use the cooperative loop (measured crossover:
 	                              // 256 triangles 15.7 vs 15.1 ms, 128: 6.1 vs 9.1 ms, 512: 31.6 vs 21.8 ms, loop vs walk)
@@ -740,19 +741,26 @@ int wbrt_render_shards(wbrt_context *ctx, const wbrt_camera *camera, int32_t num
 		if (rc) return rc;
 	}
 	HIP_TRY(hipMemsetAsync(device_image, 0, bytes, (hipStream_t)stream));
-	// This rank's shards in ONE launch where possible (2, 4, ... 64 adjacent lanes per pixel, one per shard, run the pixel's
-	// streams of all shards concurrently; one lane then adds the sums to the pixel in shard order: the same sums in the same
-	// order as the launches below, and the launch lasts as long as its longest SHARD stream, not the pixel's streams in a row):
-	// 2 to 64 shards whose sample counts are equal or drop by one once (wbrt_split_spp's pattern), at least 1 sample each.
+	// This rank's shards in ONE launch where possible: 2 to 64 shards whose sample counts are equal or drop by one once
+	// (wbrt_split_spp's pattern), at least 1 sample each.  Either 2, 4, ... 64 adjacent lanes per pixel, one per shard, run the
+	// pixel's streams of all shards concurrently and one lane then adds the sums to the pixel in shard order (the launch lasts as
+	// long as its longest SHARD stream), or one lane per pixel runs the shards in turn: the same sums in the same order as the
+	// launches below either way.
 	{
 		std::vector<int32_t> mine;
 		for (int32_t v = rank; v < num_shards; v += world) mine.push_back(v);
 		const int n = (int)mine.size();
 		// (scenes with a hierarchy over their boxes keep one launch per shard: their render build has no fused form)
 		bool fusable = ctx->fuse_shards && n >= 2 && n <= 64 && !(ctx->top_depth > 0 && walks_hierarchies(ctx));
-		int lanes_log2 = 1;
-		while ((1 << lanes_log2) < n) ++lanes_log2;
-		if ((((long long)camera->width * camera->height) << lanes_log2) >= (1LL << 36)) fusable = false; // launch grid limit
+		// Concurrent lanes per pixel where the frame is bound by its longest pixel stream: few pixels per lane the machine
+		// holds (headline frame, 0.9 M pixels: 11.12 -> 10.94 ms per 8 shards); larger frames are bound by throughput and
+		// run the shards in turn in one lane (3840x2160: 332 ms concurrently, 323 ms in turn; 1920x1080 mesh: 103.7 / 97.1 ms).
+		int lanes_log2 = 0;
+		if ((long long)camera->width * camera->height <= (long long)ctx->shard_lanes_max_pixels)
+		{
+			lanes_log2 = 1;
+			while ((1 << lanes_log2) < n) ++lanes_log2;
+		}
 		int first_spp = 0, n_full = n;
 		for (int k = 0; k < n && fusable; ++k)
 		{
@@ -1084,6 +1092,7 @@ int wbrt_tune_(wbrt_context *ctx, const char *key, int value)
 	else if (k == "bvh_min_idle") ctx->bvh_steal_min_idle = value;
 	else if (k == "strict_loop_max") ctx->strict_loop_max = value;
 	else if (k == "fuse_shards") ctx->fuse_shards = value != 0;
+	else if (k == "shard_lanes_max_pixels") ctx->shard_lanes_max_pixels = value;
 	else if (k == "wg_kernel")
 	{
 		if (value != 0 && value != 4 && value != 8) return fail(WBRT_ERR_INVALID, "wg_kernel takes 0, 4 or 8 (waves per workgroup)");

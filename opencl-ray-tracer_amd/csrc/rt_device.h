@@ -90,9 +90,9 @@ struct RenderParams
 	                                // (indexed by work index, whatever the launch order)
 	const int *order;               // optional: waves (groups of 64 work indices) sorted by estimated cost, descending
 	const uint32_t *seeds;
-	// fused seed shards (n_shards > 1): ONE launch renders n_shards shards per pixel concurrently, 2^shard_lanes_log2 (>= n_shards)
-	// adjacent lanes per pixel, and adds every shard's sum to the pixel in shard order (out_mode 2).  Shard k reads
-	// seeds + k * seeds_stride and takes spp samples, one less from shard n_full on.
+	// fused seed shards (n_shards > 1): ONE launch renders n_shards shards per pixel and adds every shard's sum to the pixel in
+	// shard order (out_mode 2): concurrently, 2^shard_lanes_log2 (>= n_shards) adjacent lanes per pixel, or (shard_lanes_log2 ==
+	// 0) in turn in one lane.  Shard k reads seeds + k * seeds_stride and takes spp samples, one less from shard n_full on.
 	int shard_lanes_log2;
 	int n_shards, n_full, seeds_stride;
 	int tolerant;                   // 1: the tolerant arithmetic build of the render kernel (render launches only)

@@ -288,8 +288,8 @@ hipError_t wbrt_launch_render(const RenderParams &p, hipStream_t stream)
 	if (p.n_shards > 1)
 	{
 		// fused seed shards (accumulating launches of scenes without a hierarchy over the boxes; the caller checks)
-		if (box_tree || p.out_mode != 2 || !p.out || p.costs || p.shard_lanes_log2 < 1 || p.shard_lanes_log2 > 6 ||
-		    p.n_shards > (1 << p.shard_lanes_log2)) return hipErrorInvalidValue;
+		if (box_tree || p.out_mode != 2 || !p.out || p.costs || p.shard_lanes_log2 < 0 || p.shard_lanes_log2 > 6 ||
+		    (p.shard_lanes_log2 > 0 && p.n_shards > (1 << p.shard_lanes_log2))) return hipErrorInvalidValue;
 		if (((long long)p.bsx * p.bsy * p.nbx * p.nby << p.shard_lanes_log2) > 0xFFFFFFFFLL * 64) return hipErrorInvalidValue;
 		if (p.tolerant)
 		{

@@ -492,8 +492,8 @@ def test_workgroup_kernel_equals_per_wave_kernel(waves):
 @pytest.mark.parametrize("name,shards", [("readme", 8), ("mesh", 8), ("readme", 32), ("mesh", 32)])
 def test_fused_seed_shards_equal_one_launch_per_shard(name, shards):
     """wbrt_render_shards renders a rank's shards in one launch (adjacent lanes run a pixel's streams of the shards
-    concurrently, one lane adds their sums in shard order); the accumulation buffer must hold exactly what one accumulating
-    launch per shard leaves, for every split of the shards over ranks (2 to 32 shards per rank, also counts that are no
+    concurrently and one lane adds their sums in shard order, or one lane runs them in turn: the form large frames take); the
+    accumulation buffer must hold exactly what one accumulating launch per shard leaves, for every split of the shards over ranks (2 to 32 shards per rank, also counts that are no
     power of two), with the schedule taken from a pilot and from recorded costs, in both arithmetic modes."""
     import torch
     if name == "readme":
@@ -511,15 +511,17 @@ def test_fused_seed_shards_equal_one_launch_per_shard(name, shards):
             for world in ((1, 2, 3, 8) if shards == 8 else (1, 5, 8)):
                 for rank in range(world if shards == 8 else min(world, 2)):
                     got = {}
-                    for fuse in (0, 1, 1):  # the second fused frame is scheduled from the first one's recorded costs
+                    # one launch per shard; the fused launch with concurrent lanes per pixel (twice: the second frame is scheduled
+                    # from the first one's recorded costs); the fused launch with the shards in turn in one lane (twice)
+                    for form, (fuse, max_pixels) in enumerate(((0, 1 << 20), (1, 1 << 20), (1, 1 << 20), (1, 0), (1, 0))):
                         ctx.tune("fuse_shards", fuse)
+                        ctx.tune("shard_lanes_max_pixels", max_pixels)
                         ctx.render_shards(cam, buf.data_ptr(), shards, 77, rank, world, spp)
                         torch.cuda.synchronize()
-                        img = buf.cpu().numpy().copy()
-                        if fuse in got:
-                            assert np.array_equal(bits(img), bits(got[fuse])), (arith, world, rank, "recorded costs")
-                        got[fuse] = img
-                    assert np.array_equal(bits(got[1]), bits(got[0])), (arith, world, rank)
+                        got[form] = buf.cpu().numpy().copy()
+                    ctx.tune("shard_lanes_max_pixels", 1 << 20)
+                    for form in range(1, 5):
+                        assert np.array_equal(bits(got[form]), bits(got[0])), (arith, world, rank, form)
         # sample counts outside the pattern that can be fused take the loop over the shards
         odd = [3, 7, 1, 2, 2, 9, 4, 4]
         cam.samplesPerPixel = max(odd)
