@@ -178,10 +178,11 @@ int wbrt_make_seeds_device(wbrt_context *ctx, uint64_t base_seed, uint32_t shard
  * Side effect: the context's seed buffer afterwards holds the seeds of this rank's shards, not what wbrt_upload_seeds
  * put there; upload again before a render that is to use other seeds.  Arguments are validated before device_image
  * is touched.
- * A rank's shards run as ONE kernel launch where their sample counts allow (2 to 8 shards, counts equal or dropping by
- * one once, as wbrt_split_spp deals them; scenes without a hierarchy over their boxes): every lane renders its pixel's
- * stream of each shard in turn and adds each sum to the pixel — the same sums in the same order as one accumulating
- * launch per shard (which is what runs otherwise), bit for bit. */
+ * A rank's shards run as ONE kernel launch where their sample counts allow (2 to 64 shards, counts equal or dropping by
+ * one once, as wbrt_split_spp deals them; scenes without a hierarchy over their boxes): on frames of up to 2^20 pixels 2, 4,
+ * ... 64 adjacent lanes per pixel run the pixel's streams of the shards concurrently and one lane adds their sums to the
+ * pixel in shard order; on larger frames one lane per pixel runs the shards in turn.  Either way: the same sums in the same
+ * order as one accumulating launch per shard (which is what runs otherwise), bit for bit. */
 int wbrt_render_shards(wbrt_context *ctx, const wbrt_camera *camera, int32_t num_shards, const int32_t *shard_spp,
                        uint64_t base_seed, int32_t rank, int32_t world, void *device_image, void *stream);
 
