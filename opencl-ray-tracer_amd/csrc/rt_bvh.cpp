@@ -25,6 +25,10 @@
 #include <cstring>
 #include <cstdlib>
 
+#ifndef WBRT_KLEAF
+#define WBRT_KLEAF 4 // triangles per leaf at most (build knob: 2, 6 and 8 measured no better)
+#endif
+
 namespace {
 
 struct Bounds
@@ -88,7 +92,7 @@ struct Builder
 		return levels;
 	}
 
-	static constexpr int kLeaf = 4, kBins = 16;
+	static constexpr int kLeaf = WBRT_KLEAF, kBins = 16;
 
 	int make_leaf(int first, int count)
 	{
@@ -221,7 +225,7 @@ struct MarginBuilder
 	int max_depth = 0;
 	double rd; // nominal R |d| the margins are priced at
 
-	static constexpr int kLeaf = 4, kBins = 16, kKeys = 6, kDirs = 13;
+	static constexpr int kLeaf = WBRT_KLEAF, kBins = 16, kKeys = 6, kDirs = 13;
 
 	static int balanced_levels(int count)
 	{
