@@ -19,7 +19,7 @@ for sname in ("f1_car", "stress"):
         pkg.lib().wbrt_dbg_rounds_(out, 1)
         ctx.set_timing(True); ctx.render_frame(cam); ms, n = ctx.get_timing(); ctx.set_timing(False)
         pkg.lib().wbrt_dbg_rounds_(out, 1)
-        r, busy, inner, leaf, rin, sleaf, sinner = [int(x) for x in out[:7]]
-        print("%s %s: %.1f ms; %.2f M wave-rounds (%.2f M with inner nodes), lanes busy %.1f%%; lane visits: inner %.1f M (sphere hierarchy %.1f M), leaf slots %.1f M (spheres %.1f M)" % (
-            sname, name, ms, r / 1e6, rin / 1e6, 100.0 * busy / max(r * 64, 1), inner / 1e6, sinner / 1e6, leaf / 1e6, sleaf / 1e6), flush=True)
+        r, busy, inner, leaf, rin, sleaf, sinner, top = [int(x) for x in out[:8]]
+        print("%s %s: %.1f ms; %.2f M wave-rounds (%.2f M with inner nodes), lanes busy %.1f%%; lane visits: inner %.1f M (sphere hierarchy %.1f M), leaf slots %.1f M (spheres %.1f M); %.2f M wave-rounds over the hierarchy of the boxes" % (
+            sname, name, ms, r / 1e6, rin / 1e6, 100.0 * busy / max(r * 64, 1), inner / 1e6, sinner / 1e6, leaf / 1e6, sleaf / 1e6, top / 1e6), flush=True)
     ctx.close()
