@@ -616,27 +616,33 @@ int wbrt_upload_scene(wbrt_context *ctx, const wbrt_sphere *spheres, int32_t S,
 		UP(bvh_nodes[variant], bnodes); UP(bvh_tris[variant], btris); UP(bvh_roots[variant], broots); UP(bvh_pairs[variant], bpairs);
 		if (variant == 1)
 		{
-			// m-box components as bytes, rounded outwards: lower bounds down, upper bounds up (b -> b/127 - 1)
-			auto pack = [](const float *v, bool up) {
-				unsigned w = 0;
+			// m-box of a child as centre and half-extent, three bytes each: centre byte b -> b/127 - 1 (nearest), half-extent
+			// byte b -> b/127, rounded up so that the stored box contains [lo, hi]
+			auto pack = [](const float *lo, const float *hi, unsigned &centre, unsigned &half) {
+				centre = half = 0;
 				for (int a = 0; a < 3; ++a)
 				{
-					const double x = ((double)v[a] + 1.0) * 127.0;
-					double b = up ? std::ceil(x) : std::floor(x);
-					if (up && b / 127.0 - 1.0 < (double)v[a]) b += 1.0;
-					if (!up && b / 127.0 - 1.0 > (double)v[a]) b -= 1.0;
-					if (!(b >= 0.0)) b = 0.0;        // also NaN: the widest box
-					if (!(b <= 254.0)) b = 254.0;
-					if (!(v[a] == v[a])) b = up ? 254.0 : 0.0;
-					w |= (unsigned)b << (8 * a);
+					double bc = 127.0, bh = 255.0; // NaN or out of range: the widest box
+					const double l = lo[a], h = hi[a];
+					if (l >= -1.0 && h <= 1.0 && l <= h)
+					{
+						bc = std::floor((0.5 * (l + h) + 1.0) * 127.0 + 0.5);
+						bc = std::min(std::max(bc, 0.0), 254.0);
+						const double c = bc / 127.0 - 1.0, need = std::max(h - c, c - l);
+						bh = std::ceil(need * 127.0);
+						while (bh / 127.0 < need) bh += 1.0;
+						bh = std::min(std::max(bh, 0.0), 255.0);
+					}
+					centre |= (unsigned)bc << (8 * a);
+					half |= (unsigned)bh << (8 * a);
 				}
-				return w;
 			};
 			std::vector<uint4> mb(bvh.nodes.size());
 			for (size_t n = 0; n < bvh.nodes.size(); ++n)
 			{
 				const float *m = &bvh.mbox[12 * n];
-				mb[n] = make_uint4(pack(m, false), pack(m + 3, true), pack(m + 6, false), pack(m + 9, true));
+				pack(m, m + 3, mb[n].x, mb[n].y);
+				pack(m + 6, m + 9, mb[n].z, mb[n].w);
 			}
 			UP(bvh_mbox, mb);
 		}

@@ -53,8 +53,8 @@ struct SceneDev
 	                          // p0.x p0.x' p0.y p0.y' | p0.z p0.z' e0.x e0.x' | e0.y e0.y' e0.z e0.z' | e1.x e1.x' e1.y e1.y' | e1.z e1.z' pos pos'
 	                          // (pos: position in the grouped order as int bits; pos' = -1: no second triangle)
 	const float4 *bvh_roots;  // 2 per box: min.xyz ref | max.xyz E   (E < 0: box without triangles)
-	const uint4  *bvh_mbox;   // 1 per node (proven-margin trees only): bytes 0-2 of x|y|z|w = left lo, left hi, right lo, right hi of the
-	                          // children's m-boxes, m = (e0 x e1)/(|e0||e1|), byte b -> b/127 - 1
+	const uint4  *bvh_mbox;   // 1 per node (proven-margin trees only): bytes 0-2 of x|y|z|w = left centre, left half-extent, right centre,
+	                          // right half-extent of the children's m-boxes, m = (e0 x e1)/(|e0||e1|); centre byte b -> b/127 - 1, half-extent b/127
 	float bvh_rho;
 	int sph_tree;             // 1: bvh_roots[B] is a hierarchy over the spheres (leaf slot: center.xyz r^2 | - | - index - -)
 	int bvh_box_slots;        // stack entries free for queued boxes: WBRT_BVH_STACK - tree depth + 1
