@@ -4,6 +4,8 @@
 //   kind 1: the four 16-byte reads of a record from one lane, in four instructions (the walk's node fetch)
 //   kind 2: the four lanes of a quad read the four 16-byte words of one record in one instruction, four instructions for
 //           the quad's four records (same bytes as kind 1, a quarter of the distinct lines per instruction)
+//   kind 3 / 4: kind 1 with half of the lanes switched off: lanes 32-63 (eight full quads left) / every other lane (all
+//           sixteen quads still touched) — does a read cost per lane or per quad of lanes?
 // Occupancy is held to 16 one-wave workgroups per CU by LDS, as in the walk.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -25,7 +27,9 @@ __global__ __launch_bounds__(64) void k(const float4 *table, unsigned mask, int 
 			const float4 a = table[4 * (size_t)idx];
 			acc += a.x;
 		}
-		if (KIND == 1)
+		if (KIND == 3 && threadIdx.x >= 32) continue;
+		if (KIND == 4 && (threadIdx.x & 1)) continue;
+		if (KIND == 1 || KIND == 3 || KIND == 4)
 		{
 			const float4 a = table[4 * (size_t)idx], b = table[4 * (size_t)idx + 1], c = table[4 * (size_t)idx + 2], d = table[4 * (size_t)idx + 3];
 			acc += a.x + b.y + c.z + d.w;
@@ -66,6 +70,8 @@ int main()
 		run<0>("one read per record", table, n, 1, out);
 		run<1>("four reads of a record from one lane", table, n, 4, out);
 		run<2>("a record's four words from the four lanes of a quad", table, n, 4, out);
+		run<3>("four reads from one lane, lanes 0-31 only (x2 = per active lane)", table, n, 2, out);
+		run<4>("four reads from one lane, even lanes only (x2 = per active lane)", table, n, 2, out);
 	}
 	return 0;
 }
