@@ -4,6 +4,7 @@
 //   kind 1: the four 16-byte reads of a record from one lane, in four instructions (the walk's node fetch)
 //   kind 2: the four lanes of a quad read the four 16-byte words of one record in one instruction, four instructions for
 //           the quad's four records (same bytes as kind 1, a quarter of the distinct lines per instruction)
+//   kind 5 / 6: one 4-byte / one 8-byte read per record (is the rate one of lane-reads or of bytes?)
 //   kind 3 / 4: kind 1 with half of the lanes switched off: lanes 32-63 (eight full quads left) / every other lane (all
 //           sixteen quads still touched) — does a read cost per lane or per quad of lanes?
 // Occupancy is held to 16 one-wave workgroups per CU by LDS, as in the walk.
@@ -27,6 +28,8 @@ __global__ __launch_bounds__(64) void k(const float4 *table, unsigned mask, int 
 			const float4 a = table[4 * (size_t)idx];
 			acc += a.x;
 		}
+		if (KIND == 5) acc += reinterpret_cast<const float *>(table)[16 * (size_t)idx];
+		if (KIND == 6) { const float2 a = reinterpret_cast<const float2 *>(table)[8 * (size_t)idx]; acc += a.x + a.y; }
 		if (KIND == 3 && threadIdx.x >= 32) continue;
 		if (KIND == 4 && (threadIdx.x & 1)) continue;
 		if (KIND == 1 || KIND == 3 || KIND == 4)
@@ -70,6 +73,8 @@ int main()
 		run<0>("one read per record", table, n, 1, out);
 		run<1>("four reads of a record from one lane", table, n, 4, out);
 		run<2>("a record's four words from the four lanes of a quad", table, n, 4, out);
+		run<5>("one 4-byte read per record (lane-reads of 4 B)", table, n, 1, out);
+		run<6>("one 8-byte read per record (lane-reads of 8 B)", table, n, 1, out);
 		run<3>("four reads from one lane, lanes 0-31 only (x2 = per active lane)", table, n, 2, out);
 		run<4>("four reads from one lane, even lanes only (x2 = per active lane)", table, n, 2, out);
 	}
