@@ -44,7 +44,7 @@ template <int KIND> void run(const char *name, int per_iter, int blocks_per_cu, 
 int main()
 {
 	float *out; hipMalloc(&out, sizeof(float) * 256 * 8 * 256);
-	for (int occ : {1, 2, 4}) {
+	for (int occ : {1, 2, 4, 6, 8}) {
 		run<0>("v_fma_f32", 128, occ, out);
 		run<1>("v_mul_f32/v_add_f32", 128, occ, out);
 		run<2>("v_pk_fma_f32", 128, occ, out);
