@@ -4,7 +4,7 @@ remarks (no GPU needed).  Usage: python scripts/kernel_resources.py > profiles/r
 import os, re, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 csrc = os.path.join(root, "opencl-ray-tracer_amd", "csrc")
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
        "-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-o", "/dev/null", "rt_kernels.hip"]
 err = subprocess.run(cmd, cwd=csrc, capture_output=True, text=True).stderr
 rows, cur = [], None

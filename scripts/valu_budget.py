@@ -171,7 +171,24 @@ def classify(chain, ranges, marks):
     return "loop glue: depth check, outcome selects, sky modulate"
 
 
-def table(path):
+# measured issue cost of a VALU instruction with 6 waves per SIMD, cycles at 2.4 GHz (scripts/ubench/valu_rate.hip)
+FAST_OPS = ("v_fma_f32", "v_fmac_f32", "v_fmaak_f32", "v_fmamk_f32", "v_mul_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_add_u32", "v_sub_u32",
+            "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_mov_b32")
+
+
+def op_cycles(op):
+    base = op[:-4] if op.endswith(("_e32", "_e64")) else op
+    base = base.replace("_dpp", "").replace("_sdwa", "")
+    if base.startswith(("v_rcp_", "v_sqrt_", "v_rsq_", "v_exp_", "v_log_", "v_sin_", "v_cos_")):
+        return 8.06, "transcendental"
+    if base.startswith("v_pk_"):
+        return 4.45, "packed"
+    if base in FAST_OPS:
+        return 2.6, "fma / mul / add / move / simple integer"
+    return 4.2, "other (min / max / compare / select / convert / shift / 3-operand integer / multiply)"
+
+
+def table(path, by_op=False):
     counts = json.load(open(path))
     ph = counts["phases"]
     S = counts.get("spheres", 5)
@@ -198,8 +215,10 @@ def table(path):
         if kind is None:
             continue
         row = classify(chain, ranges, marks)
-        rows.setdefault(row, {"valu": 0, "salu": 0, "smem": 0, "lds": 0, "vmem": 0, "trans": 0})
+        rows.setdefault(row, {"valu": 0, "salu": 0, "smem": 0, "lds": 0, "vmem": 0, "trans": 0, "ops": {}})
         rows[row][kind] += 1
+        if kind == "valu":
+            rows[row]["ops"][op] = rows[row]["ops"].get(op, 0) + 1
         if op.startswith(("v_rcp_", "v_sqrt_", "v_rsq_")):
             rows[row]["trans"] += 1
     it = ph["iterations"]["wave_executions"]
@@ -245,6 +264,36 @@ def table(path):
             p = ph["div_by_const fallbacks"]
             return p["wave_executions"], p["lanes"]
         return waves, waves * 64
+    if by_op:
+        # the same budget by opcode, priced with the measured issue cost of each instruction class
+        scale = 250.0 / counts["spp"]
+        ops, classes, by_phase = {}, {}, {}
+        for row, c in rows.items():
+            e, _ = execs(row)
+            for op, n in c["ops"].items():
+                cyc, cls = op_cycles(op)
+                ops[op] = ops.get(op, 0.0) + n * e * scale
+                classes[cls] = classes.get(cls, [0.0, 0.0])
+                classes[cls][0] += n * e * scale
+                classes[cls][1] += n * e * scale * cyc
+                by_phase[row] = by_phase.get(row, [0.0, 0.0])
+                by_phase[row][0] += n * e * scale
+                by_phase[row][1] += n * e * scale * cyc
+        tot_n = sum(v[0] for v in classes.values())
+        tot_c = sum(v[1] for v in classes.values())
+        print("VALU wave-instructions of the headline launch by issue class (static counts x wave-level executions; cost per instruction")
+        print("measured with 6 waves per SIMD, scripts/ubench/valu_rate.hip -> profiles/r3/valu_issue_rates.txt)")
+        for cls, (n, cy) in sorted(classes.items(), key=lambda kv: -kv[1][1]):
+            print("  %-92s %10.4g inst %5.1f%%   x %.2f cycles = %5.1f%% of the issue cycles" % (cls, n, 100 * n / tot_n, cy / n, 100 * cy / tot_c))
+        print("  total %.4g instructions, %.4g issue cycles = %.2f ms on 1024 SIMDs at 2.4 GHz (mean %.2f cycles per instruction)" % (
+            tot_n, tot_c, tot_c / 1024 / 2.4e9 * 1e3, tot_c / tot_n))
+        print("by phase (issue cycles):")
+        for row, (n, cy) in sorted(by_phase.items(), key=lambda kv: -kv[1][1])[:14]:
+            print("  %-82s %10.4g inst  %5.1f%% of the cycles  (%.2f cycles per instruction)" % (row, n, 100 * cy / tot_c, cy / n))
+        print("the 25 most issued opcodes:")
+        for op, n in sorted(ops.items(), key=lambda kv: -kv[1])[:25]:
+            print("  %-28s %10.4g  %4.1f%%  %.2f cycles" % (op, n, 100 * n / tot_n, op_cycles(op)[0]))
+        return
     total = 0.0
     out = []
     for row, c in rows.items():
@@ -270,5 +319,7 @@ def table(path):
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "run":
         run(int(sys.argv[2]) if len(sys.argv) > 2 else 250)
+    elif len(sys.argv) > 1 and sys.argv[1] == "ops":
+        table(sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", "phase_counts.json"), by_op=True)
     else:
         table(sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", "phase_counts.json"))
