@@ -22,4 +22,13 @@ tiles = costs[:H - H % 8, :W - W % 8].reshape(H // 8, 8, W // 8, 8).max(axis=(1,
 ts = np.sort(tiles)[::-1]
 for k in (1, 4, 16, 64, 256, 1024):
     print("  %5d-th longest tile (its longest lane): %d iterations" % (k, ts[k - 1]))
-ctx.close()
+
+# the tile of the longest stream: its 64 lanes, sorted
+costs = costs[:H - H % 8, :W - W % 8]
+y, x = np.unravel_index(np.argmax(costs), costs.shape)
+tile = costs[y // 8 * 8:y // 8 * 8 + 8, x // 8 * 8:x // 8 * 8 + 8]
+print("tile of the longest stream (pixel %d,%d): lanes sorted:" % (x, y), np.sort(tile.ravel())[::-1].tolist())
+for k in (1, 2, 3):
+    yy, xx = np.unravel_index(np.argsort(costs.ravel())[::-1][k * 5], costs.shape)
+    t2 = costs[yy // 8 * 8:yy // 8 * 8 + 8, xx // 8 * 8:xx // 8 * 8 + 8]
+    print("tile of the %d-th longest stream: top lanes" % (k * 5 + 1), np.sort(t2.ravel())[::-1][:12].tolist(), "median", int(np.median(t2)))
